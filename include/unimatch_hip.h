@@ -1,0 +1,126 @@
+/*
+ * unimatch_hip.h — C ABI of the MI355X (gfx950) global-matching hot path.
+ *
+ * The reference (autonomousvision/unimatch) has no FFI: its hot path is a set of Python functions
+ * made of ATen ops.  Each entry point below replaces ONE of those functions with one fused HIP
+ * launch sequence; the citation on each is the reference function it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only, no torch types.  All pointers are DEVICE pointers.
+ *   - The caller owns every buffer (inputs, outputs, workspace).  The library never allocates or
+ *     frees device memory and never keeps a pointer after the call returns.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and performs no host synchronisation.  Stateless and re-entrant.
+ *   - Return value: 0 = enqueued; negative = argument error (UM_ERR_*); positive = hipError_t.
+ *     um_last_error_string() describes the last failure on the calling thread.
+ *   - Feature tensors are "token major": [N, L, C] fp32, L = h*w tokens in row-major (y, x) order,
+ *     C = 128 channels contiguous per token (the transpose of the reference's [N, C, h, w]).
+ *     Flow-like outputs are [N, V, h, w] fp32 exactly as the reference returns them.
+ *   - `mode` selects the operand precision of the MFMA contractions:
+ *       UM_MODE_EXACT  fp16 hi+lo split operands, 3 MFMA products per tile, fp32 accumulate
+ *                      (~2^-22 relative operand error: meets the fp32 reference to its own noise floor)
+ *       UM_MODE_FAST   bf16 operands, 1 MFMA product per tile, fp32 accumulate
+ *     Softmax, accumulators and all non-MFMA kernels are fp32 in both modes.
+ */
+#ifndef UNIMATCH_HIP_H
+#define UNIMATCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UM_VERSION 100
+
+#define UM_MODE_EXACT 0
+#define UM_MODE_FAST 1
+
+#define UM_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unsupported channel count ... */
+#define UM_ERR_BAD_GEOMETRY (-2) /* window does not tile the map, shift >= window ...             */
+#define UM_ERR_WORKSPACE (-3)    /* workspace missing or too small                                  */
+#define UM_ERR_UNSUPPORTED (-4)  /* valid in the reference but not implemented by this library      */
+
+int um_version(void);
+const char* um_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Windowed single-head attention  softmax(q k^T / sqrt(C) + shift_mask) v   inside windows.
+ * Replaces (one geometry each):
+ *   unimatch/attention.py:45-104  single_head_split_window_attention   win=(h/K,w/K), shift=win/2|0
+ *   unimatch/attention.py:8-16    single_head_full_attention           win=(h,w)
+ *   unimatch/attention.py:19-42   single_head_full_attention_1d        win=(1,w)
+ *   unimatch/attention.py:107-163 single_head_split_window_attention_1d win=(1,w/K), shift=(0,win_w/2)|0
+ * together with torch.roll, split_feature/merge_splits (unimatch/utils.py:34-81,155-196) and the
+ * additive -100 masks (unimatch/utils.py:84-108,199-216), which become index arithmetic.
+ * q, k, v, out: [streams, h*w, C] fp32.  C must be 128.
+ * ------------------------------------------------------------------------------------------- */
+size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode);
+int um_window_attn_fwd(const float* q, const float* k, const float* v, float* out,
+                       int streams, int h, int w, int channels,
+                       int win_h, int win_w, int shift_h, int shift_w,
+                       int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * All-pairs correlation + softmax + expected coordinate (flow).
+ * Replaces unimatch/matching.py:7-36 global_correlation_softmax (the [B,L,L] correlation and
+ * probability tensors are never formed).  f0, f1: [B, h*w, C].  flow: [B or 2B, 2, h, w]
+ * (bidir != 0 appends the backward flow, matching.py:23-27).
+ * ------------------------------------------------------------------------------------------- */
+size_t um_global_corr_workspace_bytes(int batch, int tokens, int channels, int mode);
+int um_global_corr_softmax_flow(const float* f0, const float* f1, float* flow,
+                                int batch, int h, int w, int channels, int bidir,
+                                int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-scanline W x W correlation, targets right of the query masked, disparity = x - E[x'].
+ * Replaces unimatch/matching.py:126-151 global_correlation_softmax_stereo.  disp: [B, 1, h, w]. */
+int um_global_corr_softmax_stereo(const float* f0, const float* f1, float* disp,
+                                  int batch, int h, int w, int channels,
+                                  int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Global self-attention propagation  softmax(q k^T / sqrt(C)) value.
+ * Replaces the attention core of unimatch/attention.py:196-213 SelfAttnPropagation.forward
+ * (q/k projections stay with the caller).  q, k: [B, h*w, C]; value, out: [B, V, h, w], V in {1,2}. */
+int um_prop_global_attn(const float* q, const float* k, const float* value, float* out,
+                        int batch, int h, int w, int channels, int value_channels,
+                        int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Local-window kernels (fp32 VALU, wavefront-shuffle reductions; `mode` does not apply).
+ * ------------------------------------------------------------------------------------------- */
+
+/* (2r+1)^2 (or 2r+1 when one_d) integer-offset correlation, out-of-image taps -> -1e9, softmax,
+ * expected offset.  Replaces unimatch/matching.py:39-83 local_correlation_softmax (flow [B,2,h,w])
+ * and :154-200 local_correlation_softmax_stereo (one_d != 0: returns -flow_x as [B,1,h,w]). */
+int um_local_corr_softmax(const float* f0, const float* f1, float* out,
+                          int batch, int h, int w, int channels, int radius, int one_d, void* stream);
+
+/* Local cost volume at flow-displaced positions: out[k,p] = f0(p) . bilinear(f1, p + d_k + flow(p)) / sqrt(C),
+ * zeros outside.  Replaces unimatch/matching.py:86-123 local_correlation_with_flow (dilation 1).
+ * flow: [B, 2, h, w]; cost: [B, (2r+1)^2, h, w]. */
+int um_local_corr_with_flow(const float* f0, const float* f1, const float* flow, float* cost,
+                            int batch, int h, int w, int channels, int radius, void* stream);
+
+/* (2r+1)^2 local self-attention propagation with zero-padded keys/values (out-of-image neighbours
+ * have logit 0, value 0 and take part in the softmax).
+ * Replaces the core of unimatch/attention.py:217-253 forward_local_window_attn. */
+int um_prop_local_attn(const float* q, const float* k, const float* value, float* out,
+                       int batch, int h, int w, int channels, int value_channels, int radius,
+                       void* stream);
+
+/* Plane-sweep depth correlation + softmax over D inverse-depth candidates + soft-argmin / argmax.
+ * Replaces unimatch/matching.py:203-282 correlation_softmax_depth + warp_with_pose_depth_candidates.
+ * cam: [B, 30] fp32 per-sample camera constants, row major:  K^-1 (9) | R (9) | t (3) | K (9), with K the
+ * intrinsics already divided by the feature stride (unimatch/unimatch.py:147-150) and [R|t] the relative
+ * pose; the kernel applies them in the reference's order (back-project, rotate, scale by depth, translate,
+ * project, clamp z >= 1e-3).  candidates: [D] inverse depths.  out: [B, 1, h, w] inverse depth. */
+int um_depth_corr_softmax(const float* f0, const float* f1, const float* cam, const float* candidates,
+                          float* out, int batch, int h, int w, int channels, int num_candidates,
+                          int from_argmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIMATCH_HIP_H */

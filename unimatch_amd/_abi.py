@@ -1,0 +1,71 @@
+"""ctypes binding of ``libunimatch_hip.so`` (the C ABI declared in ``include/unimatch_hip.h``).
+
+There is deliberately NO fallback: if the library is missing or a symbol cannot be resolved the import
+of the hot path fails loudly.  The product never computes the hot path any other way.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libunimatch_hip.so')
+
+MODE_EXACT = 0
+MODE_FAST = 1
+
+_c_int, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/unimatch_hip.h one to one
+SIGNATURES = {
+    'um_version': (_c_int, []),
+    'um_last_error_string': (ctypes.c_char_p, []),
+    'um_window_attn_workspace_bytes': (_c_size_t, [_c_int] * 4),
+    'um_window_attn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_global_corr_workspace_bytes': (_c_size_t, [_c_int] * 4),
+    'um_global_corr_softmax_flow': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_global_corr_softmax_stereo': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_prop_global_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_local_corr_softmax': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
+    'um_local_corr_with_flow': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    'um_prop_local_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
+    'um_depth_corr_softmax': (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and attach prototypes.  Raises HipExtensionError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f'{LIB_PATH} is missing: build it with `python -m unimatch_amd.build` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the hot path.')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise HipExtensionError(f'cannot load {LIB_PATH}: {exc}') from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise HipExtensionError(f'{LIB_PATH} does not export {name}') from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    """Translate the C ABI's return convention into Python exceptions."""
+    if code == 0:
+        return
+    msg = load().um_last_error_string().decode('utf-8', 'replace')
+    if code < 0:
+        raise ValueError(f'{what}: {msg} (code {code})')
+    raise RuntimeError(f'{what}: HIP error {code}')

@@ -1,0 +1,58 @@
+"""Build recipe for the HIP extension: ``hipcc --offload-arch=gfx950`` -> ``unimatch_amd/libunimatch_hip.so``.
+
+In-tree on purpose: the built ``.so`` travels with a snapshot of the repository (it is git-ignored, so the
+history stays source-only).  hipcc cross-compiles without a GPU.  Usage: ``python -m unimatch_amd.build``.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libunimatch_hip.so')
+SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip']
+HEADERS = ['common.h', 'planes.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
+
+
+def find_hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: the HIP extension cannot be built')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
+    hipcc = find_hipcc()
+    objdir = os.path.join(HERE, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True, cwd=CSRC)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.  gfx950 only: no other-arch paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UM_CHANNELS 128          // feature channels of every UniMatch variant (unimatch/unimatch.py:19)
+#define UM_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define UM_LOG2E 1.4426950408889634f
+#define UM_NEG_INIT (-1.0e30f)   // running-max start value
+#define UM_NEG_MASK (-2.0e30f)   // excluded score: strictly below UM_NEG_INIT so exp2(s - m) == 0 even
+                                 // for a lane that has not met a valid key yet
+
+// ---- 16-bit element traits -------------------------------------------------------------------
+// Fp16: used with hi+lo split operands ("exact" mode).  Bf16: single operand ("fast" mode).
+struct Fp16 {
+    static __device__ __forceinline__ unsigned short down(float x) {
+        _Float16 h = (_Float16)x;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ float up(unsigned short b) {
+        return (float)__builtin_bit_cast(_Float16, b);
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        f32x2 v = {a, b};
+        f16x2 h = __builtin_convertvector(v, f16x2);
+        return __builtin_bit_cast(unsigned, h);
+    }
+    static __device__ __forceinline__ f32x2 unpack2(unsigned u) {
+        f16x2 h = __builtin_bit_cast(f16x2, u);
+        return __builtin_convertvector(h, f32x2);
+    }
+    static __device__ __forceinline__ f32x16 mfma(i16x8 a, i16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct Bf16 {
+    static __device__ __forceinline__ unsigned short down(float x) {
+        __bf16 h = (__bf16)x;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ float up(unsigned short b) {
+        return __builtin_bit_cast(float, ((unsigned)b) << 16);
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        f32x2 v = {a, b};
+        bf16x2 h = __builtin_convertvector(v, bf16x2);
+        return __builtin_bit_cast(unsigned, h);
+    }
+    static __device__ __forceinline__ f32x2 unpack2(unsigned u) {
+        f32x2 r = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+        return r;
+    }
+    static __device__ __forceinline__ f32x16 mfma(i16x8 a, i16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// ---- MFMA 32x32x16 fragment conventions (wave64) ---------------------------------------------
+//   A (32 x 16): lane l holds A[m = l & 31][k = 8 * (l >> 5) + j], j = 0..7   (16 contiguous bytes)
+//   B (16 x 32): lane l holds B[k = 8 * (l >> 5) + j][n = l & 31]
+//   D (32 x 32): lane l, reg r holds D[m = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][n = l & 31]
+// All kernels compute "swapped" products D = K . Q^T so that n = query: every lane owns one query
+// row and the softmax reductions are in-lane plus one exchange with lane ^ 32.
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ i16x8 ld_global_16B(const unsigned short* p) {
+    return *reinterpret_cast<const i16x8*>(p);
+}
+
+// XCD-aware remap of a linear workgroup id: the dispatcher places consecutive ids on consecutive
+// XCDs (id % 8); this gives every XCD a contiguous range of logical ids so that workgroups sharing
+// K/V (query tiles of one window) hit the same L2.  Bijective for any total.  Speed only.
+__device__ __forceinline__ int xcd_remap(int id, int total) {
+    const int nx = 8;
+    int q = total / nx, r = total % nx;
+    int xcd = id % nx, k = id / nx;
+    int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}

@@ -1,0 +1,454 @@
+// Local-window kernels: short fp32 dot products against a handful of neighbouring tokens.   gfx950 / wave64
+//
+//   um_local_corr_softmax     unimatch/matching.py:39-83, 154-200   (2r+1)^2 / (2r+1) taps, softmax, E[offset]
+//   um_local_corr_with_flow   unimatch/matching.py:86-123           (2r+1)^2 bilinear taps at p + d + flow(p)
+//   um_prop_local_attn        unimatch/attention.py:217-253         (2r+1)^2 zero-padded self-attention taps
+//   um_depth_corr_softmax     unimatch/matching.py:203-282          D plane-sweep candidates, soft-argmin
+//
+// These are gather + short-reduction kernels (arithmetic intensity of a few flop/byte): they are bounded by
+// L2/HBM bandwidth and VALU issue, not by the matrix cores, so they are NOT reshaped into GEMMs.  The
+// reference materialises a [B, L, C, taps] gathered tensor for each of them (1.0-1.3 GB per pair per call
+// for the cost volume); here nothing but the [taps] logits of one pixel ever exists, in registers.
+//
+// Common structure: one wavefront per pixel, lanes = 16 tap slots x 4 channel quarters.  A lane holds 32
+// channels of f0(p) in registers, reads 128 contiguous bytes of the neighbour token (4 lanes cover the
+// 512-byte token row: coalesced), does 32 FMAs and the 4 quarter sums are combined with two DPP-class
+// shuffles.  Taps are processed 16 per round.  Softmax statistics are reduced across the 16 slots with
+// four more shuffles.  Token-major feature layout [B, L, 128] fp32.
+#include "common.h"
+
+#define LOCAL_MAX_ROUNDS 8      // up to 128 taps / depth candidates
+
+__device__ __forceinline__ void load32(f32x4 (&r)[8], const float* p) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = reinterpret_cast<const f32x4*>(p)[i];
+}
+
+__device__ __forceinline__ float dot32(const f32x4 (&a)[8], const float* p) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 b = reinterpret_cast<const f32x4*>(p)[i];
+        acc = __builtin_fmaf(a[i][0], b[0], acc);
+        acc = __builtin_fmaf(a[i][1], b[1], acc);
+        acc = __builtin_fmaf(a[i][2], b[2], acc);
+        acc = __builtin_fmaf(a[i][3], b[3], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float quad_sum(float v) {      // sum over the 4 channel quarters (lanes 4k..4k+3)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+__device__ __forceinline__ float slot_max(float v) {      // reduce over the 16 tap slots (lane bits 2..5)
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float slot_sum(float v) {
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: local correlation + softmax + expected offset
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float* __restrict__ f0,
+                                                                 const float* __restrict__ f1,
+                                                                 float* __restrict__ out, int batch, int h, int w,
+                                                                 int radius, int one_d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w;
+    const long total = (long)batch * L;
+    const int kw = 2 * radius + 1;
+    const int ntaps = one_d ? kw : kw * kw;
+    const int rounds = (ntaps + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
+        const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+        const int y = p / w, x = p - y * w;
+        f32x4 a[8];
+        load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+        float logit[LOCAL_MAX_ROUNDS];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            logit[r] = -3.0e38f;
+            if (r < rounds) {
+                const int t = r * 16 + slot;
+                const int dy = one_d ? 0 : t / kw - radius;
+                const int dx = (one_d ? t : t % kw) - radius;
+                const int yy = y + dy, xx = x + dx;
+                const bool tap = t < ntaps;
+                const bool ok = tap && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                float d = 0.f;
+                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                d = quad_sum(d);
+                // out-of-image taps take part with logit -1e9 (matching.py:73); slots beyond ntaps do not exist
+                logit[r] = tap ? (ok ? d * scale : -1.0e9f) : -3.0e38f;
+                mx = fmaxf(mx, logit[r]);
+            }
+        }
+        mx = slot_max(mx);
+        float sp = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            if (r < rounds) {
+                const int t = r * 16 + slot;
+                const float e = t < ntaps ? __expf(logit[r] - mx) : 0.f;
+                const int dy = one_d ? 0 : t / kw - radius;
+                const int dx = (one_d ? t : t % kw) - radius;
+                sp += e;
+                sx += e * (float)dx;
+                sy += e * (float)dy;
+            }
+        }
+        sp = slot_sum(sp);
+        sx = slot_sum(sx);
+        sy = slot_sum(sy);
+        if (lane == 0) {
+            if (one_d) {
+                out[pid] = -(sx / sp);                       // disparity residual = -flow_x (matching.py:198)
+            } else {
+                out[((long)b * 2 + 0) * L + p] = sx / sp;
+                out[((long)b * 2 + 1) * L + p] = sy / sp;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4: local cost volume at flow-displaced positions (input of the regression refinement)
+// All (2r+1)^2 taps of a pixel share one fractional offset and bilinear sampling is linear in f1, so the
+// kernel computes the (2r+2)^2 integer-position dot products around floor(p + flow) once and blends 4 of
+// them per tap: 100 dots instead of 81 x 4 gathers for r = 4.  Out-of-image corners contribute 0 (zeros pad).
+// A wave walks 16 consecutive pixels and stages its [taps][16] outputs in LDS so that the [B, taps, h, w]
+// volume is written in 64-byte runs.
+// ------------------------------------------------------------------------------------------------------
+#define K4_PIX 16
+#define K4_MAX_TAPS 81
+#define K4_MAX_DOTS 100
+__global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* __restrict__ f0,
+                                                                   const float* __restrict__ f1,
+                                                                   const float* __restrict__ flow,
+                                                                   float* __restrict__ cost, int batch, int h, int w,
+                                                                   int radius) {
+    __shared__ float dots_s[4][K4_MAX_DOTS + 4];
+    __shared__ float tile_s[4][K4_MAX_TAPS][K4_PIX + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w;
+    const long total = (long)batch * L;
+    const int kw = 2 * radius + 1, n1 = kw + 1;
+    const int ntaps = kw * kw, ndots = n1 * n1;
+    const int rounds = (ndots + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    const long nblocks = (total + K4_PIX - 1) / K4_PIX;
+    for (long pb = (long)blockIdx.x * 4 + wave; pb < nblocks; pb += (long)gridDim.x * 4) {
+        const long p0 = pb * K4_PIX;
+        for (int j = 0; j < K4_PIX; ++j) {
+            const long pid = p0 + j;
+            if (pid >= total) break;
+            const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+            const int y = p / w, x = p - y * w;
+            const float px = (float)x + flow[((long)b * 2 + 0) * L + p];
+            const float py = (float)y + flow[((long)b * 2 + 1) * L + p];
+            const float fbx = floorf(px), fby = floorf(py);
+            const float wx = px - fbx, wy = py - fby;
+            // clamp far-away bases so the int conversion is defined; such samples are all-zero anyway
+            const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f);
+            const int by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
+            f32x4 a[8];
+            load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+            for (int r = 0; r < rounds; ++r) {
+                const int t = r * 16 + slot;
+                const int iy = t / n1, ix = t - iy * n1;
+                const int yy = by + iy - radius, xx = bx + ix - radius;
+                const bool ok = t < ndots && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                float d = 0.f;
+                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                d = quad_sum(d);
+                if (quarter == 0 && t < ndots) dots_s[wave][t] = d;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy);
+            const float w10 = (1.f - wx) * wy, w11 = wx * wy;
+            for (int k = lane; k < ntaps; k += 64) {
+                const int ty = k / kw, tx = k - ty * kw;
+                const float* dd = &dots_s[wave][ty * n1 + tx];
+                const float v = w00 * dd[0] + w01 * dd[1] + w10 * dd[n1] + w11 * dd[n1 + 1];
+                tile_s[wave][k][j] = v * scale;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // write the [taps][16] tile: 16 consecutive pixels of one tap are contiguous in the volume
+        for (int idx = lane; idx < ntaps * K4_PIX; idx += 64) {
+            const int k = idx / K4_PIX, j = idx - k * K4_PIX;
+            const long pid = p0 + j;
+            if (pid < total) {
+                const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+                cost[((long)b * ntaps + k) * L + p] = tile_s[wave][k][j];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K6: local self-attention propagation.  Out-of-image neighbours have key 0 -> logit 0 and value 0, and
+// they DO take part in the softmax (zero padding of F.unfold, attention.py:234-246).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prop_local_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ value,
+                                                              float* __restrict__ out, int batch, int h, int w,
+                                                              int vch, int radius) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w;
+    const long total = (long)batch * L;
+    const int kw = 2 * radius + 1;
+    const int ntaps = kw * kw;
+    const int rounds = (ntaps + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
+        const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+        const int y = p / w, x = p - y * w;
+        f32x4 a[8];
+        load32(a, q + pid * UM_CHANNELS + 32 * quarter);
+        float logit[LOCAL_MAX_ROUNDS], v0[LOCAL_MAX_ROUNDS], v1[LOCAL_MAX_ROUNDS];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            logit[r] = -3.0e38f;
+            v0[r] = v1[r] = 0.f;
+            if (r < rounds) {
+                const int t = r * 16 + slot;
+                const int dy = t / kw - radius, dx = t % kw - radius;
+                const int yy = y + dy, xx = x + dx;
+                const bool tap = t < ntaps;
+                const bool ok = tap && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                float d = 0.f;
+                if (ok) {
+                    d = dot32(a, k + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                    v0[r] = value[((long)b * vch) * L + yy * w + xx];
+                    if (vch == 2) v1[r] = value[((long)b * vch + 1) * L + yy * w + xx];
+                }
+                d = quad_sum(d);
+                logit[r] = tap ? d * scale : -3.0e38f;     // d == 0 for padded neighbours
+                mx = fmaxf(mx, logit[r]);
+            }
+        }
+        mx = slot_max(mx);
+        float sp = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            if (r < rounds) {
+                const float e = (r * 16 + slot) < ntaps ? __expf(logit[r] - mx) : 0.f;
+                sp += e;
+                s0 += e * v0[r];
+                s1 += e * v1[r];
+            }
+        }
+        sp = slot_sum(sp);
+        s0 = slot_sum(s0);
+        s1 = slot_sum(s1);
+        if (lane == 0) {
+            out[((long)b * vch) * L + p] = s0 / sp;
+            if (vch == 2) out[((long)b * vch + 1) * L + p] = s1 / sp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K7: plane-sweep depth correlation.  For every inverse-depth candidate the pixel is back-projected,
+// moved by the relative pose, re-projected (same operation order as matching.py:259-270), feature1 is
+// sampled bilinearly with zero padding and correlated with feature0; softmax over candidates.
+// cam: per sample 30 floats = Kinv[9] | R[9] | t[3] | K[9], row major.
+// The [B, C, D, h, w] warped volume of the reference (2.5 GB at B=16, 480x640) never exists.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __restrict__ f0,
+                                                                 const float* __restrict__ f1,
+                                                                 const float* __restrict__ cam,
+                                                                 const float* __restrict__ cand,
+                                                                 float* __restrict__ out, int batch, int h, int w,
+                                                                 int nd, int from_argmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w;
+    const long total = (long)batch * L;
+    const int rounds = (nd + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
+        const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+        const int y = p / w, x = p - y * w;
+        const float* cm = cam + (long)b * 30;
+        const float gx = (float)x, gy = (float)y;
+        // ray = R (Kinv [x y 1]^T)
+        const float r0 = cm[0] * gx + cm[1] * gy + cm[2];
+        const float r1 = cm[3] * gx + cm[4] * gy + cm[5];
+        const float r2 = cm[6] * gx + cm[7] * gy + cm[8];
+        const float q0 = cm[9] * r0 + cm[10] * r1 + cm[11] * r2;
+        const float q1 = cm[12] * r0 + cm[13] * r1 + cm[14] * r2;
+        const float q2 = cm[15] * r0 + cm[16] * r1 + cm[17] * r2;
+        f32x4 a[8];
+        load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+        float logit[LOCAL_MAX_ROUNDS], cv[LOCAL_MAX_ROUNDS];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            logit[r] = -3.0e38f;
+            cv[r] = 0.f;
+            if (r < rounds) {
+                const int t = r * 16 + slot;
+                const bool tap = t < nd;
+                const float ci = cand[tap ? t : 0];
+                cv[r] = ci;
+                const float depth = 1.0f / ci;
+                const float X = q0 * depth + cm[18], Y = q1 * depth + cm[19], Z = q2 * depth + cm[20];
+                const float u = cm[21] * X + cm[22] * Y + cm[23] * Z;
+                const float v = cm[24] * X + cm[25] * Y + cm[26] * Z;
+                const float zz = fmaxf(cm[27] * X + cm[28] * Y + cm[29] * Z, 1e-3f);
+                const float sx = fminf(fmaxf(u / zz, -1.0e6f), 1.0e6f);
+                const float sy = fminf(fmaxf(v / zz, -1.0e6f), 1.0e6f);
+                const float fx0 = floorf(sx), fy0 = floorf(sy);
+                const float wx = sx - fx0, wy = sy - fy0;
+                const int x0 = (int)fx0, y0 = (int)fy0;
+                float d = 0.f;
+                if (tap) {
+#pragma unroll
+                    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                        for (int cx = 0; cx < 2; ++cx) {
+                            const int yy = y0 + cy, xx = x0 + cx;
+                            if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                                const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
+                                d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                            }
+                        }
+                }
+                d = quad_sum(d);
+                logit[r] = tap ? d * scale : -3.0e38f;
+                mx = fmaxf(mx, logit[r]);
+            }
+        }
+        mx = slot_max(mx);
+        float sp = 0.f, sc = 0.f;
+        float best = -3.0e38f;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+            if (r < rounds) {
+                const int t = r * 16 + slot;
+                const float e = t < nd ? __expf(logit[r] - mx) : 0.f;
+                sp += e;
+                sc += e * cv[r];
+                if (t < nd && logit[r] > best) { best = logit[r]; besti = t; }
+            }
+        }
+        sp = slot_sum(sp);
+        sc = slot_sum(sc);
+        float res = sc / sp;
+        if (from_argmax) {   // first index attaining the maximum
+            const int cand_i = (best == mx) ? besti : 0x7fffffff;
+            int mi = cand_i;
+            mi = min(mi, __shfl_xor(mi, 4));
+            mi = min(mi, __shfl_xor(mi, 8));
+            mi = min(mi, __shfl_xor(mi, 16));
+            mi = min(mi, __shfl_xor(mi, 32));
+            res = cand[mi];
+        }
+        if (lane == 0) out[pid] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+extern void um_set_error(const char* fmt, ...);
+
+static int local_check(const void* a, const void* b, const void* c, int batch, int h, int w, int channels) {
+    if (!a || !b || !c || batch <= 0 || h <= 0 || w <= 0) {
+        um_set_error("null pointer or non-positive size (batch=%d h=%d w=%d)", batch, h, w);
+        return -1;
+    }
+    if (channels != UM_CHANNELS) {
+        um_set_error("channels=%d unsupported (the library is built for %d)", channels, UM_CHANNELS);
+        return -1;
+    }
+    return 0;
+}
+
+static unsigned pixel_grid_blocks(long pixels) {
+    long blocks = (pixels + 3) / 4;
+    const long cap = 256 * 16;           // 16 workgroups per CU, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int um_local_corr_softmax(const float* f0, const float* f1, float* out, int batch, int h, int w,
+                                     int channels, int radius, int one_d, void* stream) {
+    if (int e = local_check(f0, f1, out, batch, h, w, channels)) return e;
+    const int kw = 2 * radius + 1;
+    if (radius < 1 || (one_d ? kw : kw * kw) > 16 * LOCAL_MAX_ROUNDS) {
+        um_set_error("radius=%d unsupported (at most %d taps)", radius, 16 * LOCAL_MAX_ROUNDS);
+        return -4;
+    }
+    hipLaunchKernelGGL(local_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
+                       (hipStream_t)stream, f0, f1, out, batch, h, w, radius, one_d);
+    return (int)hipGetLastError();
+}
+
+extern "C" int um_local_corr_with_flow(const float* f0, const float* f1, const float* flow, float* cost, int batch,
+                                       int h, int w, int channels, int radius, void* stream) {
+    if (int e = local_check(f0, f1, cost, batch, h, w, channels)) return e;
+    if (!flow) {
+        um_set_error("flow is null");
+        return -1;
+    }
+    if (radius < 1 || (2 * radius + 1) * (2 * radius + 1) > K4_MAX_TAPS) {
+        um_set_error("radius=%d unsupported (at most %d taps)", radius, K4_MAX_TAPS);
+        return -4;
+    }
+    const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
+    hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0,
+                       (hipStream_t)stream, f0, f1, flow, cost, batch, h, w, radius);
+    return (int)hipGetLastError();
+}
+
+extern "C" int um_prop_local_attn(const float* q, const float* k, const float* value, float* out, int batch, int h,
+                                  int w, int channels, int value_channels, int radius, void* stream) {
+    if (int e = local_check(q, k, out, batch, h, w, channels)) return e;
+    if (!value || (value_channels != 1 && value_channels != 2)) {
+        um_set_error("value_channels=%d: the reference propagates flow (2) or disparity/depth (1)", value_channels);
+        return -1;
+    }
+    if (radius < 1 || (2 * radius + 1) * (2 * radius + 1) > 16 * LOCAL_MAX_ROUNDS) {
+        um_set_error("radius=%d unsupported (at most %d taps)", radius, 16 * LOCAL_MAX_ROUNDS);
+        return -4;
+    }
+    hipLaunchKernelGGL(prop_local_attn_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
+                       (hipStream_t)stream, q, k, value, out, batch, h, w, value_channels, radius);
+    return (int)hipGetLastError();
+}
+
+extern "C" int um_depth_corr_softmax(const float* f0, const float* f1, const float* cam, const float* candidates,
+                                     float* out, int batch, int h, int w, int channels, int num_candidates,
+                                     int from_argmax, void* stream) {
+    if (int e = local_check(f0, f1, out, batch, h, w, channels)) return e;
+    if (!cam || !candidates || num_candidates < 1 || num_candidates > 16 * LOCAL_MAX_ROUNDS) {
+        um_set_error("num_candidates=%d unsupported (1..%d)", num_candidates, 16 * LOCAL_MAX_ROUNDS);
+        return -4;
+    }
+    hipLaunchKernelGGL(depth_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
+                       (hipStream_t)stream, f0, f1, cam, candidates, out, batch, h, w, num_candidates, from_argmax);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,71 @@
+"""CNN feature encoder (stays on PyTorch-ROCm / MIOpen: dense convolutions are outside the hot path).
+
+Architecture and parameter names follow /root/reference/unimatch/backbone.py:39-133 and
+unimatch/trident_conv.py:10-90 so that reference checkpoints load unchanged
+(``backbone.conv1.weight``, ``backbone.layer2.0.downsample.0.bias``, ``backbone.trident_conv.weight`` ...).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+
+
+class _Residual(nn.Module):
+    """Two 3x3 convs with InstanceNorm + ReLU, projection shortcut when the shape changes."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1, self.conv2 = _conv3(cin, cout, stride), _conv3(cout, cout)
+        self.norm1, self.norm2 = nn.InstanceNorm2d(cout), nn.InstanceNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.norm3 = nn.InstanceNorm2d(cout)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = F.relu(self.norm1(self.conv1(x)))
+        y = F.relu(self.norm2(self.conv2(y)))
+        return F.relu((x if self.downsample is None else self.downsample(x)) + y)
+
+
+class _SharedStridedConv(nn.Module):
+    """One 3x3 weight applied at strides 1, 2, 4... ("trident" multi-scale branches, no bias)."""
+
+    def __init__(self, channels, num_branch):
+        super().__init__()
+        self.num_branch = num_branch
+        self.weight = nn.Parameter(torch.empty(channels, channels, 3, 3))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity='relu')
+
+    def forward(self, x):
+        return [F.conv2d(x, self.weight, None, stride=2 ** i, padding=1) for i in range(self.num_branch)]
+
+
+class CNNEncoder(nn.Module):
+    """1/8 features (one scale) or 1/4 + 1/8 features (two scales, weight-shared strided conv)."""
+
+    def __init__(self, output_dim=128, num_output_scales=1):
+        super().__init__()
+        self.num_branch = num_output_scales
+        d0, d1, d2 = 64, 96, 128
+        self.conv1 = nn.Conv2d(3, d0, 7, stride=2, padding=3, bias=False)
+        self.norm1 = nn.InstanceNorm2d(d0)
+        self.layer1 = nn.Sequential(_Residual(d0, d0, 1), _Residual(d0, d0, 1))
+        self.layer2 = nn.Sequential(_Residual(d0, d1, 2), _Residual(d1, d1, 1))
+        self.layer3 = nn.Sequential(_Residual(d1, d2, 2 if num_output_scales == 1 else 1), _Residual(d2, d2, 1))
+        self.conv2 = nn.Conv2d(d2, output_dim, 1)
+        if num_output_scales > 1:
+            if num_output_scales > 4:
+                raise ValueError('at most 4 output scales')
+            self.trident_conv = _SharedStridedConv(output_dim, num_output_scales)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def forward(self, x):
+        x = F.relu(self.norm1(self.conv1(x)))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return self.trident_conv(x) if self.num_branch > 1 else [x]       # high -> low resolution

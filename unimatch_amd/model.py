@@ -1,0 +1,397 @@
+"""Drop-in ``UniMatch`` module whose global-matching hot path runs on hand-written gfx950 HIP kernels.
+
+Boundary (what a caller sees) is the reference's own:
+``UniMatch(num_scales, feature_channels, upsample_factor, num_head, ffn_dim_expansion,
+num_transformer_layers, reg_refine, task)`` (/root/reference/unimatch/unimatch.py:17-26),
+``forward(img0, img1, attn_type, attn_splits_list, corr_radius_list, prop_radius_list, num_reg_refine,
+pred_bidir_flow, task, intrinsics, pose, min_depth, max_depth, num_depth_candidates, depth_from_argmax,
+pred_bidir_depth)`` -> ``{'flow_preds': [tensor]}`` (unimatch.py:95-111, 365-367) and the reference's
+``state_dict`` names, so ``evaluate_flow/stereo/depth`` can drive it unchanged.
+
+What is different inside:
+  * features travel token-major ``[N, h*w, C]`` through the whole hot path (no permute/copy per window split);
+  * self / cross attention is decided by the layer's role, not by a device->host sync on the data
+    (reference: ``(query - key).abs().max() < 1e-6``, transformer.py:55);
+  * attention, matching, propagation and the local cost volume are single fused HIP launches
+    (``unimatch_amd.ops.HipOps``); no L x L, n x n or [B, L, C, taps] tensor is ever materialised;
+  * inference only (the reference's training-mode extra outputs are out of scope).
+The CNN encoder, Linear/LayerNorm/FFN and the refinement / upsampling convolutions stay on stock
+PyTorch-ROCm ops.  There is no CPU or PyTorch fallback for the hot path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .encoder import CNNEncoder
+from .refine import BasicUpdateBlock, convex_upsample
+
+_IMAGENET_MEAN = (0.485, 0.456, 0.406)
+_IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def attention_windows(attn_type, is_self, splits, h, w, with_shift):
+    """(win_h, win_w, shift_h, shift_w) of one attention layer.
+
+    Dispatch table of the reference (transformer.py:62-135) with the self/cross role made structural.
+    2-D swin: K x K windows; 'row': every scanline; 'winrow': K windows per scanline; 'full': whole map.
+    """
+    if attn_type == 'swin':
+        kind = 'win2d'
+    elif attn_type == 'self_swin2d_cross_1d':
+        kind = 'win2d' if is_self else 'row'
+    elif attn_type == 'self_swin2d_cross_swin1d':
+        kind = 'win2d' if is_self else 'winrow'
+    else:
+        kind = 'full'
+    if splits <= 1:
+        kind = {'win2d': 'full', 'winrow': 'row'}.get(kind, kind)
+    if kind == 'full':
+        return h, w, 0, 0
+    if kind == 'row':
+        return 1, w, 0, 0
+    if kind == 'win2d':
+        if h % splits or w % splits:
+            raise AssertionError(f'feature map {h}x{w} is not divisible by attn_splits={splits}')
+        wh, ww = h // splits, w // splits
+        return (wh, ww, wh // 2, ww // 2) if with_shift else (wh, ww, 0, 0)
+    if w % splits:
+        raise AssertionError(f'feature width {w} is not divisible by attn_splits={splits}')
+    ww = w // splits
+    return (1, ww, 0, ww // 2) if with_shift else (1, ww, 0, 0)
+
+
+def sine_position_tokens(win_h, win_w, reps_h, reps_w, channels):
+    """Token-major ``[reps_h*win_h*reps_w*win_w, C]`` sine position table (fp32, CPU).
+
+    Same arithmetic, in the same order, as the reference's DETR embedding evaluated on a window-sized grid
+    (position.py:26-46, utils.py:114-124): normalised to 2*pi with eps 1e-6, temperature 10000, y features in
+    the first C/2 channels.  The table is tiled over the reps_h x reps_w windows.
+    """
+    half = channels // 2
+    ys = torch.arange(1, win_h + 1, dtype=torch.float32)
+    xs = torch.arange(1, win_w + 1, dtype=torch.float32)
+    ys = ys / (ys[-1] + 1e-6) * (2 * math.pi)
+    xs = xs / (xs[-1] + 1e-6) * (2 * math.pi)
+    j = torch.arange(half, dtype=torch.float32)
+    dim_t = 10000.0 ** (2 * torch.div(j, 2, rounding_mode='floor') / half)
+
+    def enc(v):
+        ang = v[:, None] / dim_t
+        out = torch.empty_like(ang)
+        out[:, 0::2] = ang[:, 0::2].sin()
+        out[:, 1::2] = ang[:, 1::2].cos()
+        return out
+
+    ey, ex = enc(ys), enc(xs)                                   # [win_h, half], [win_w, half]
+    tab = torch.cat([ey[:, None, :].expand(win_h, win_w, half), ex[None, :, :].expand(win_h, win_w, half)], -1)
+    return tab.repeat(reps_h, reps_w, 1).reshape(-1, channels).contiguous()
+
+
+class TransformerLayer(nn.Module):
+    """Attention (+ optional FFN) layer; parameters as in transformer.py:9-40, forward via HipOps."""
+
+    def __init__(self, d_model, no_ffn, ffn_dim_expansion):
+        super().__init__()
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.no_ffn = no_ffn
+        if not no_ffn:
+            self.mlp = nn.Sequential(nn.Linear(2 * d_model, 2 * d_model * ffn_dim_expansion, bias=False), nn.GELU(),
+                                     nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
+            self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, ops, source, target, h, w, geom):
+        q, k, v = self.q_proj(source), self.k_proj(target), self.v_proj(target)
+        msg = ops.window_attention(q, k, v, h, w, *geom)
+        msg = self.norm1(self.merge(msg))
+        if not self.no_ffn:
+            msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
+        return source + msg
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, d_model, ffn_dim_expansion):
+        super().__init__()
+        self.self_attn = TransformerLayer(d_model, True, ffn_dim_expansion)
+        self.cross_attn_ffn = TransformerLayer(d_model, False, ffn_dim_expansion)
+
+
+class FeatureTransformer(nn.Module):
+    """6 x (self-attention, cross-attention + FFN) on both images at once (transformer.py:203-294)."""
+
+    def __init__(self, num_layers=6, d_model=128, nhead=1, ffn_dim_expansion=4):
+        super().__init__()
+        if nhead != 1:
+            raise NotImplementedError('multi-head attention is not implemented (neither does the reference, '
+                                      'transformer.py:63-66)')
+        self.d_model = d_model
+        self.layers = nn.ModuleList([TransformerBlock(d_model, ffn_dim_expansion) for _ in range(num_layers)])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, ops, tok0, tok1, h, w, attn_type, attn_num_splits):
+        """tok0, tok1: ``[B, h*w, C]`` token-major features (position already added)."""
+        b = tok0.shape[0]
+        stream = torch.cat([tok0, tok1], 0)            # updated stream  [f0; f1]
+        other = torch.cat([tok1, tok0], 0)             # cross-attention target [f1; f0]
+        for i, blk in enumerate(self.layers):
+            shift = ('swin' in attn_type) and attn_num_splits > 1 and i % 2 == 1
+            g_self = attention_windows(attn_type, True, attn_num_splits, h, w, shift)
+            g_cross = attention_windows(attn_type, False, attn_num_splits, h, w, shift)
+            stream = blk.self_attn(ops, stream, stream, h, w, g_self)
+            stream = blk.cross_attn_ffn(ops, stream, other, h, w, g_cross)
+            other = torch.cat([stream[b:], stream[:b]], 0)
+        return stream[:b].contiguous(), stream[b:].contiguous()
+
+
+class SelfAttnPropagation(nn.Module):
+    """Flow propagation with feature self-similarity (attention.py:166-253); parameters only."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.q_proj = nn.Linear(in_channels, in_channels)
+        self.k_proj = nn.Linear(in_channels, in_channels)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, ops, tok0, flow, h, w, local_window_attn=False, local_window_radius=1):
+        q = self.q_proj(tok0)
+        if local_window_attn:
+            return ops.prop_local(q, self.k_proj(tok0), flow, h, w, local_window_radius)
+        # reference quirk kept on purpose: the global path projects the *query* again (attention.py:198-205)
+        return ops.prop_global(q, self.k_proj(q), flow, h, w)
+
+
+def _to_tokens(fmap):
+    return fmap.flatten(2).transpose(1, 2).contiguous()
+
+
+def _to_map(tokens, h, w):
+    b, _, c = tokens.shape
+    return tokens.transpose(1, 2).reshape(b, c, h, w)
+
+
+def _pixel_grid(h, w, device):
+    ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
+                            torch.arange(w, device=device, dtype=torch.float32), indexing='ij')
+    return torch.stack([xs, ys], 0)
+
+
+def _warp(fmap, flow):
+    """Bilinear warp with zero padding, align_corners (geometry.py:41-72); torch op, not on the hot path."""
+    b, c, h, w = fmap.shape
+    pos = _pixel_grid(h, w, fmap.device)[None] + flow
+    grid = torch.stack([2 * pos[:, 0] / (w - 1) - 1, 2 * pos[:, 1] / (h - 1) - 1], -1)
+    return F.grid_sample(fmap, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+def _rigid_flow(depth, intrinsics, pose):
+    """Flow induced by depth and relative pose (geometry.py:99-195)."""
+    b, h, w = depth.shape
+    grid = _pixel_grid(h, w, depth.device)
+    homog = torch.cat([grid, torch.ones(1, h, w, device=depth.device)], 0).flatten(1)
+    pts = (torch.inverse(intrinsics) @ homog) * depth.view(b, 1, -1)
+    pts = pose[:, :3, :3] @ pts + pose[:, :3, 3:]
+    proj = intrinsics @ pts
+    return (proj[:, :2] / proj[:, 2:].clamp(min=1e-3)).view(b, 2, h, w) - grid
+
+
+class UniMatch(nn.Module):
+    def __init__(self, num_scales=1, feature_channels=128, upsample_factor=8, num_head=1, ffn_dim_expansion=4,
+                 num_transformer_layers=6, reg_refine=False, task='flow'):
+        super().__init__()
+        if feature_channels != 128:
+            raise NotImplementedError('the HIP kernels are built for feature_channels=128 '
+                                      '(the value of every released UniMatch model)')
+        self.feature_channels = feature_channels
+        self.num_scales = num_scales
+        self.upsample_factor = upsample_factor
+        self.reg_refine = reg_refine
+        self.backbone = CNNEncoder(output_dim=feature_channels, num_output_scales=num_scales)
+        self.transformer = FeatureTransformer(num_layers=num_transformer_layers, d_model=feature_channels,
+                                              nhead=num_head, ffn_dim_expansion=ffn_dim_expansion)
+        self.feature_flow_attn = SelfAttnPropagation(in_channels=feature_channels)
+        if not reg_refine or task == 'depth':
+            self.upsampler = nn.Sequential(nn.Conv2d(2 + feature_channels, 256, 3, 1, 1), nn.ReLU(inplace=True),
+                                           nn.Conv2d(256, upsample_factor ** 2 * 9, 1, 1, 0))
+        if reg_refine:
+            self.refine_proj = nn.Conv2d(128, 256, 1)
+            self.refine = BasicUpdateBlock(corr_channels=(2 * 4 + 1) ** 2, downsample_factor=upsample_factor,
+                                           flow_dim=2 if task == 'flow' else 1, bilinear_up=task == 'depth')
+        # not part of the state_dict: hot-path backend and caches
+        self._ops = None
+        self._precision = 'exact'
+        self._pos_cache = {}
+
+    # ------------------------------------------------------------------ hot-path backend
+    def set_precision(self, precision):
+        """'exact' (fp16 hi+lo split MFMA operands; parity mode) or 'fast' (bf16 operands)."""
+        self._precision = precision
+        self._ops = None
+        return self
+
+    def bind_ops(self, ops):
+        """Install a hot-path backend explicitly (tests inject the CPU oracle here)."""
+        self._ops = ops
+        return self
+
+    @property
+    def ops(self):
+        if self._ops is None:
+            from .ops import HipOps           # raises when the HIP extension or the GPU is missing
+            self._ops = HipOps(self._precision)
+        return self._ops
+
+    def _position(self, h, w, splits, device):
+        key = (h, w, splits, str(device))
+        if key not in self._pos_cache:
+            if splits > 1:
+                tab = sine_position_tokens(h // splits, w // splits, splits, splits, self.feature_channels)
+            else:
+                tab = sine_position_tokens(h, w, 1, 1, self.feature_channels)
+            self._pos_cache[key] = tab.to(device)
+        return self._pos_cache[key]
+
+    def _upsample(self, flow2, f0_map, is_depth=False):
+        mask = self.upsampler(torch.cat([flow2, f0_map], 1))
+        return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img0, img1, attn_type=None, attn_splits_list=None, corr_radius_list=None,
+                prop_radius_list=None, num_reg_refine=1, pred_bidir_flow=False, task='flow', intrinsics=None,
+                pose=None, min_depth=1. / 0.5, max_depth=1. / 10, num_depth_candidates=64,
+                depth_from_argmax=False, pred_bidir_depth=False, **kwargs):
+        if self.training:
+            raise RuntimeError('this module implements inference only: call .eval() '
+                               '(training-mode auxiliary outputs of the reference are out of scope)')
+        if pred_bidir_flow:
+            assert task == 'flow'
+        if task == 'depth':
+            assert self.num_scales == 1
+            assert len(attn_splits_list) == len(prop_radius_list) == self.num_scales == 1
+        else:
+            assert len(attn_splits_list) == len(corr_radius_list) == len(prop_radius_list) == self.num_scales
+        ops = self.ops
+        attn_type = attn_type if attn_type is not None else ''
+        dev = img0.device
+
+        with torch.no_grad():
+            if task == 'flow':                  # stereo / depth loaders normalise already (unimatch.py:122-124)
+                mean = torch.tensor(_IMAGENET_MEAN, device=dev).view(1, 3, 1, 1)
+                std = torch.tensor(_IMAGENET_STD, device=dev).view(1, 3, 1, 1)
+                img0, img1 = (img0 / 255. - mean) / std, (img1 / 255. - mean) / std
+            feats = self.backbone(torch.cat([img0, img1], 0))[::-1]         # low -> high resolution
+            nb = img0.shape[0]
+            flow, pred = None, None
+            for s in range(self.num_scales):
+                m0, m1 = feats[s][:nb], feats[s][nb:]                         # [B, C, h, w]
+                if pred_bidir_flow and s > 0:
+                    m0, m1 = torch.cat([m0, m1], 0), torch.cat([m1, m0], 0)
+                h, w = m0.shape[-2:]
+                ori0, ori1 = _to_tokens(m0), _to_tokens(m1)                   # pre-position, pre-warp tokens
+                up = self.upsample_factor * 2 ** (self.num_scales - 1 - s)
+                if task == 'depth':
+                    k_cur = intrinsics.clone()
+                    k_cur[:, :2] = k_cur[:, :2] / up
+                if s > 0:
+                    flow = F.interpolate(flow, scale_factor=2, mode='bilinear', align_corners=True) * 2
+                tok1 = ori1
+                if flow is not None:
+                    assert task != 'depth'
+                    disp = torch.cat([-flow, torch.zeros_like(flow)], 1) if task == 'stereo' else flow
+                    tok1 = _to_tokens(_warp(m1, disp))
+                splits, prop_r = attn_splits_list[s], prop_radius_list[s]
+                pos = self._position(h, w, splits, dev)
+                tok0, tok1 = ori0 + pos, tok1 + pos
+                tok0, tok1 = self.transformer(ops, tok0, tok1, h, w, attn_type, splits)
+
+                # ---- matching layer
+                if task == 'depth':
+                    cand = torch.linspace(min_depth, max_depth, num_depth_candidates).to(dev).float()
+                    f0c, f1c, kc, pc = tok0, tok1, k_cur, pose
+                    if pred_bidir_depth:
+                        f0c, f1c = torch.cat([tok0, tok1], 0), torch.cat([tok1, tok0], 0)
+                        kc = k_cur.repeat(2, 1, 1)
+                        pc = torch.cat([pose, torch.inverse(pose)], 0)
+                    cam = torch.cat([torch.inverse(kc).flatten(1), pc[:, :3, :3].flatten(1), pc[:, :3, 3],
+                                     kc.flatten(1)], 1).float().contiguous()
+                    flow_pred = ops.depth_corr_softmax(f0c, f1c, h, w, cam, cand.contiguous(), depth_from_argmax)
+                else:
+                    radius = corr_radius_list[s]
+                    if radius == -1:
+                        if task == 'flow':
+                            flow_pred = ops.global_corr_softmax_flow(tok0, tok1, h, w, pred_bidir_flow)
+                        elif task == 'stereo':
+                            flow_pred = ops.global_corr_softmax_stereo(tok0, tok1, h, w)
+                        else:
+                            raise NotImplementedError
+                    else:
+                        if task not in ('flow', 'stereo'):
+                            raise NotImplementedError
+                        flow_pred = ops.local_corr_softmax(tok0, tok1, h, w, radius, one_d=(task == 'stereo'))
+                flow = flow_pred if flow is None else flow + flow_pred
+                if task == 'stereo':
+                    flow = flow.clamp(min=0)
+
+                # ---- propagation
+                if (pred_bidir_flow or pred_bidir_depth) and s == 0:
+                    tok0 = torch.cat([tok0, tok1], 0)
+                flow = self.feature_flow_attn(ops, tok0, flow.contiguous(), h, w,
+                                              local_window_attn=prop_r > 0, local_window_radius=prop_r)
+                if s < self.num_scales - 1:
+                    continue
+
+                # ---- full-resolution prediction
+                f0_map = _to_map(tok0, h, w)
+                if not self.reg_refine:
+                    if task == 'stereo':
+                        pad = torch.cat([-flow, torch.zeros_like(flow)], 1)
+                        pred = -self._upsample(pad, f0_map)[:, :1]
+                    elif task == 'depth':
+                        pad = torch.cat([flow, torch.zeros_like(flow)], 1)
+                        pred = self._upsample(pad, f0_map, is_depth=True).clamp(min=min_depth, max=max_depth)[:, :1]
+                    else:
+                        pred = self._upsample(flow, f0_map)
+                    continue
+                assert num_reg_refine > 0
+                pose_r = pose
+                proj = self.refine_proj(f0_map)                 # same every iteration (unimatch.py:315-320)
+                net0, inp = torch.tanh(proj[:, :128]), torch.relu(proj[:, 128:])
+                for it in range(num_reg_refine):
+                    if task == 'stereo':
+                        disp = torch.cat([-flow, torch.zeros_like(flow)], 1)
+                    elif task == 'depth':
+                        if pred_bidir_depth and it == 0:
+                            k_cur = k_cur.repeat(2, 1, 1)
+                            pose_r = torch.cat([pose, torch.inverse(pose)], 0)
+                            ori0, ori1 = torch.cat([ori0, ori1], 0), torch.cat([ori1, ori0], 0)
+                        disp = _rigid_flow(1. / flow.squeeze(1), k_cur, pose_r)
+                    else:
+                        disp = flow
+                    corr = ops.local_corr_with_flow(ori0, ori1, disp.contiguous(), h, w, 4)
+                    _, up_mask, delta = self.refine(net0, inp, corr, flow)
+                    if task == 'depth':
+                        flow = (flow - delta).clamp(min=min_depth, max=max_depth)
+                    else:
+                        flow = flow + delta
+                    if task == 'stereo':
+                        flow = flow.clamp(min=0)
+                    if it == num_reg_refine - 1:
+                        if task == 'depth':
+                            pad = torch.cat([flow, torch.zeros_like(flow)], 1)
+                            pred = self._upsample(pad, f0_map, is_depth=True).clamp(
+                                min=min_depth, max=max_depth)[:, :1]
+                        else:
+                            pred = convex_upsample(flow, up_mask, self.upsample_factor)
+            if task == 'stereo':
+                pred = pred.squeeze(1)
+            if task == 'depth':
+                pred = 1. / pred.squeeze(1)
+        return {'flow_preds': [pred]}

@@ -1,0 +1,192 @@
+"""Typed Python wrappers over the C ABI: one method per reference hot-path function.
+
+``HipOps`` is the ONLY implementation of the hot path that the product ships.  Every method checks
+shapes / dtypes / contiguity, allocates the output (and scratch workspace) as torch tensors, and enqueues
+the HIP kernels on torch's current stream through ``ctypes``.  Feature tensors are token-major
+``[N, L, C]`` fp32 (C = 128); flow-like tensors are ``[N, V, h, w]`` fp32 as in the reference.
+"""
+import torch
+
+from . import _abi
+
+PRECISIONS = {'exact': _abi.MODE_EXACT, 'fast': _abi.MODE_FAST}
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, meta)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, meta in self.records:
+            d = out.setdefault(name, {'calls': 0, 'ms': 0.0, 'meta': meta})
+            d['calls'] += 1
+            d['ms'] += s.elapsed_time(e)
+        return out
+
+
+def _ptr(t):
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_tokens(name, t, n=None, tokens=None):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous()):
+        raise ValueError(f'{name}: expected a contiguous CUDA float32 [N, L, C] tensor, got '
+                         f'{tuple(t.shape)} {t.dtype} {t.device} contiguous={t.is_contiguous()}')
+    if n is not None and t.shape[0] != n or tokens is not None and t.shape[1] != tokens:
+        raise ValueError(f'{name}: shape {tuple(t.shape)} does not match N={n}, L={tokens}')
+
+
+def _check_map(name, t, n, h, w):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()
+            and t.shape[0] == n and t.shape[2] == h and t.shape[3] == w):
+        raise ValueError(f'{name}: expected a contiguous CUDA float32 [{n}, V, {h}, {w}] tensor, got '
+                         f'{tuple(t.shape)} {t.dtype}')
+
+
+class HipOps:
+    """The hot path on MI355X.  ``precision``: 'exact' (fp16 hi+lo split MFMA operands) or 'fast' (bf16)."""
+
+    def __init__(self, precision='exact'):
+        if precision not in PRECISIONS:
+            raise ValueError(f'precision must be one of {sorted(PRECISIONS)}')
+        self.lib = _abi.load()                # raises HipExtensionError when the library is missing
+        if not torch.cuda.is_available():
+            raise _abi.HipExtensionError('no GPU visible: the UniMatch hot path only runs on the HIP extension')
+        self.precision = precision
+        self.mode = PRECISIONS[precision]
+        self.timer = None                     # set to a KernelTimer() to time launches with HIP events
+
+    # ------------------------------------------------------------------ helpers
+    def _ws(self, nbytes, device):
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+    def _launch(self, name, fn, meta=None):
+        if self.timer is None:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self.timer.records.append((name, s, e, meta))
+        return r
+
+    # ------------------------------------------------------------------ attention
+    def window_attention(self, q, k, v, h, w, win_h, win_w, shift_h=0, shift_w=0):
+        """softmax(q k^T/sqrt(C) + shift mask) v inside windows; q, k, v ``[S, h*w, C]``."""
+        s, l, c = q.shape
+        _check_tokens('q', q, tokens=h * w)
+        _check_tokens('k', k, s, l)
+        _check_tokens('v', v, s, l)
+        out = torch.empty_like(q)
+        nbytes = self.lib.um_window_attn_workspace_bytes(s, l, c, self.mode)
+        ws = self._ws(nbytes, q.device)
+        n = win_h * win_w
+        meta = {'flops': 4.0 * s * l * n * c, 'bytes': 4.0 * 4 * s * l * c}
+        code = self._launch('window_attn', lambda: self.lib.um_window_attn_fwd(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(out), s, h, w, c, win_h, win_w, shift_h, shift_w,
+            self.mode, _ptr(ws), ws.numel(), _stream()), meta)
+        _abi.check(code, 'um_window_attn_fwd')
+        return out
+
+    # ------------------------------------------------------------------ global matching
+    def global_corr_softmax_flow(self, f0, f1, h, w, bidir=False):
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        out = torch.empty((2 * b if bidir else b, 2, h, w), dtype=torch.float32, device=f0.device)
+        ws = self._ws(self.lib.um_global_corr_workspace_bytes(b, l, c, self.mode), f0.device)
+        meta = {'flops': (2.0 if bidir else 1.0) * b * (2.0 * l * l * c + 4.0 * l * l),
+                'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l}
+        code = self._launch('global_corr_flow', lambda: self.lib.um_global_corr_softmax_flow(
+            _ptr(f0), _ptr(f1), _ptr(out), b, h, w, c, int(bool(bidir)), self.mode,
+            _ptr(ws), ws.numel(), _stream()), meta)
+        _abi.check(code, 'um_global_corr_softmax_flow')
+        return out
+
+    def global_corr_softmax_stereo(self, f0, f1, h, w):
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        out = torch.empty((b, 1, h, w), dtype=torch.float32, device=f0.device)
+        ws = self._ws(self.lib.um_global_corr_workspace_bytes(b, l, c, self.mode), f0.device)
+        code = self._launch('global_corr_stereo', lambda: self.lib.um_global_corr_softmax_stereo(
+            _ptr(f0), _ptr(f1), _ptr(out), b, h, w, c, self.mode, _ptr(ws), ws.numel(), _stream()))
+        _abi.check(code, 'um_global_corr_softmax_stereo')
+        return out
+
+    def prop_global(self, q, k, value, h, w):
+        b, l, c = q.shape
+        _check_tokens('q', q, tokens=h * w)
+        _check_tokens('k', k, b, l)
+        _check_map('value', value, b, h, w)
+        out = torch.empty_like(value)
+        ws = self._ws(self.lib.um_global_corr_workspace_bytes(b, l, c, self.mode), q.device)
+        vch = value.shape[1]
+        meta = {'flops': b * (2.0 * l * l * c + 2.0 * l * l * vch), 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l * vch}
+        code = self._launch('prop_global', lambda: self.lib.um_prop_global_attn(
+            _ptr(q), _ptr(k), _ptr(value), _ptr(out), b, h, w, c, vch, self.mode,
+            _ptr(ws), ws.numel(), _stream()), meta)
+        _abi.check(code, 'um_prop_global_attn')
+        return out
+
+    # ------------------------------------------------------------------ local kernels (fp32)
+    def local_corr_softmax(self, f0, f1, h, w, radius, one_d=False):
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        out = torch.empty((b, 1 if one_d else 2, h, w), dtype=torch.float32, device=f0.device)
+        code = self._launch('local_corr_softmax', lambda: self.lib.um_local_corr_softmax(
+            _ptr(f0), _ptr(f1), _ptr(out), b, h, w, c, radius, int(bool(one_d)), _stream()))
+        _abi.check(code, 'um_local_corr_softmax')
+        return out
+
+    def local_corr_with_flow(self, f0, f1, flow, h, w, radius):
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        _check_map('flow', flow, b, h, w)
+        if flow.shape[1] != 2:
+            raise ValueError('flow must have 2 channels')
+        k = 2 * radius + 1
+        out = torch.empty((b, k * k, h, w), dtype=torch.float32, device=f0.device)
+        meta = {'flops': 2.0 * b * l * (k + 1) ** 2 * c, 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l + 4.0 * k * k * b * l}
+        code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow(
+            _ptr(f0), _ptr(f1), _ptr(flow), _ptr(out), b, h, w, c, radius, _stream()), meta)
+        _abi.check(code, 'um_local_corr_with_flow')
+        return out
+
+    def prop_local(self, q, k, value, h, w, radius):
+        b, l, c = q.shape
+        _check_tokens('q', q, tokens=h * w)
+        _check_tokens('k', k, b, l)
+        _check_map('value', value, b, h, w)
+        out = torch.empty_like(value)
+        code = self._launch('prop_local', lambda: self.lib.um_prop_local_attn(
+            _ptr(q), _ptr(k), _ptr(value), _ptr(out), b, h, w, c, value.shape[1], radius, _stream()))
+        _abi.check(code, 'um_prop_local_attn')
+        return out
+
+    def depth_corr_softmax(self, f0, f1, h, w, cam, candidates, from_argmax=False):
+        """cam ``[B, 30]`` = K^-1 | R | t | K (row major), candidates ``[D]`` inverse depths."""
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        if not (cam.is_cuda and cam.dtype == torch.float32 and cam.is_contiguous() and tuple(cam.shape) == (b, 30)):
+            raise ValueError(f'cam: expected contiguous CUDA float32 [{b}, 30]')
+        if not (candidates.is_cuda and candidates.dtype == torch.float32 and candidates.is_contiguous()
+                and candidates.dim() == 1):
+            raise ValueError('candidates: expected contiguous CUDA float32 [D]')
+        out = torch.empty((b, 1, h, w), dtype=torch.float32, device=f0.device)
+        code = self._launch('depth_corr_softmax', lambda: self.lib.um_depth_corr_softmax(
+            _ptr(f0), _ptr(f1), _ptr(cam), _ptr(candidates), _ptr(out), b, h, w, c,
+            candidates.numel(), int(bool(from_argmax)), _stream()))
+        _abi.check(code, 'um_depth_corr_softmax')
+        return out
