@@ -46,6 +46,21 @@ extern "C" {
 int um_version(void);
 const char* um_last_error_string(void);
 
+/* Optional measurement aid: when enabled, every launch of the kernels below is bracketed by a pair of
+ * hipEvents recorded on the launch stream itself; um_timing_collect() waits for them, returns the summed
+ * kernel time and launch count since the last collect, and recycles the events.  Off by default (then the
+ * library keeps no state at all). */
+#define UM_K_WINDOW_ATTN 0   /* window_attn_kernel (um_window_attn_fwd)                                  */
+#define UM_K_GLOBAL_SOFTMAX 1 /* gsv_kernel (um_global_corr_softmax_flow/_stereo, um_prop_global_attn)    */
+#define UM_K_SPLIT_PLANES 2  /* split_planes_kernel (operand conversion pre-pass of the MFMA kernels)     */
+#define UM_K_LOCAL_CORR 3    /* local_corr_softmax_kernel                                                */
+#define UM_K_COST_VOLUME 4   /* local_corr_with_flow_kernel                                              */
+#define UM_K_PROP_LOCAL 5    /* prop_local_attn_kernel                                                   */
+#define UM_K_DEPTH_CORR 6    /* depth_corr_softmax_kernel                                                */
+#define UM_K_COUNT 7
+int um_timing_enable(int on);
+int um_timing_collect(int kernel_id, double* total_ms, int* launches);
+
 /* ---------------------------------------------------------------------------------------------
  * Windowed single-head attention  softmax(q k^T / sqrt(C) + shift_mask) v   inside windows.
  * Replaces (one geometry each):

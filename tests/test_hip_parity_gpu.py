@@ -1,0 +1,296 @@
+"""GPU parity tests: every HIP entry point (called through the C ABI via ctypes) against the CPU oracle
+evaluated in float64, on the committed golden inputs plus seeded larger / ragged shapes, and end to end.
+
+Tolerances (written where used):
+  exact mode (fp16 hi+lo split operands, fp32 accumulate): the kernels must match an fp64 evaluation as
+  closely as the fp32 reference itself does -> abs 5e-5 on O(1) attention outputs, 2e-3 feature cells on
+  expected coordinates with +-100 logits.
+  fast mode (bf16 operands): 3e-2 relative to the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import hotpath as hp
+from oracle import model as om
+from unimatch_amd import UniMatch
+from unimatch_amd.ops import HipOps
+from unimatch_amd.synth import CONFIGS, synth_camera, synth_images, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+C = 128
+DEV = 'cuda'
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def tok(fmap):
+    return fmap.flatten(2).transpose(1, 2).contiguous()
+
+
+def err(a, b):
+    d = (a.double().cpu() - b.double().cpu()).abs()
+    return d.max().item(), d.mean().item()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    return HipOps('exact')
+
+
+@pytest.fixture(scope='module')
+def ops_fast():
+    return HipOps('fast')
+
+
+# ------------------------------------------------------------------ attention
+def _geom(tag, h, w, k, shift):
+    if tag.startswith('win2d'):
+        return (h // k, w // k, (h // k // 2) if shift else 0, (w // k // 2) if shift else 0)
+    if tag.startswith('winrow'):
+        return (1, w // k, 0, (w // k // 2) if shift else 0)
+    if tag.startswith('row'):
+        return (1, w, 0, 0)
+    return (h, w, 0, 0)
+
+
+def test_window_attention_golden_cases(ops, ops_fast, golden):
+    g = golden('attention')
+    for tag in sorted({k.split('.')[0] for k in g.keys()}):
+        h, w, k, shift = (int(x) for x in g[f'{tag}.meta'])
+        geom = _geom(tag, h, w, k, shift)
+        q, kk, v = g[f'{tag}.q'], g[f'{tag}.k'], g[f'{tag}.v']
+        want = hp.window_attention(q.double(), kk.double(), v.double(), h, w, *geom)
+        got = ops.window_attention(q.to(DEV), kk.to(DEV), v.to(DEV), h, w, *geom)
+        mx, mean = err(got, want)
+        assert mx < 5e-5 * max(1.0, want.abs().max().item()), (tag, mx, mean)
+        # the fp32 reference output stored in the fixture is just as close
+        assert err(got, g[f'{tag}.out'])[0] < 1e-4 * max(1.0, want.abs().max().item()), tag
+        got_f = ops_fast.window_attention(q.to(DEV), kk.to(DEV), v.to(DEV), h, w, *geom)
+        assert err(got_f, want)[1] < 3e-2 * want.abs().mean().item() + 1e-3, (tag, 'fast')
+
+
+@pytest.mark.parametrize('case', [
+    # streams, h, w, win_h, win_w, shift_h, shift_w, scale
+    (2, 16, 24, 8, 12, 4, 6, 1.0),        # 96-token windows: ragged 128-query tile, 2 key tiles
+    (1, 20, 28, 10, 14, 5, 7, 2.0),       # 140-token windows: 2 query tiles, ragged key tile
+    (2, 32, 48, 16, 24, 8, 12, 1.5),      # 384-token windows (config-4 scale-1 window size)
+    (1, 24, 40, 24, 40, 0, 0, 1.0),       # one full window of 960 tokens
+    (2, 6, 60, 1, 30, 0, 15, 2.0),        # config-3 style 1-D shifted windows of 30
+    (2, 5, 120, 1, 120, 0, 0, 1.0),       # full scanlines of 120
+])
+def test_window_attention_larger_shapes(ops, case):
+    s, h, w, wh, ww, sh, sw, scale = case
+    q, k, v = (rnd(10 + i, s, h * w, C, scale=scale) for i in range(3))
+    want = hp.window_attention(q.double(), k.double(), v.double(), h, w, wh, ww, sh, sw)
+    got = ops.window_attention(q.to(DEV), k.to(DEV), v.to(DEV), h, w, wh, ww, sh, sw)
+    mx, mean = err(got, want)
+    assert mx < 5e-5 * max(1.0, want.abs().max().item()), (case, mx, mean)
+
+
+def test_window_attention_forced_rescale_and_mask_dominance(ops):
+    """A spiked key far down the window forces the running max to jump late (every earlier tile must be
+    rescaled exactly once), and a masked key whose logit beats the own region by more than 100 must WIN the
+    softmax (the reference adds -100, it does not exclude)."""
+    s, h, w, wh, ww = 1, 16, 24, 8, 12
+    q, k, v = (rnd(20 + i, s, h * w, C) for i in range(3))
+    k[0, 200] = q[0, 10] * 6.0                 # token 200 strongly matches token 10's query direction
+    for (sh, sw) in ((0, 0), (4, 6)):
+        want = hp.window_attention(q.double(), k.double(), v.double(), h, w, wh, ww, sh, sw)
+        got = ops.window_attention(q.to(DEV), k.to(DEV), v.to(DEV), h, w, wh, ww, sh, sw)
+        assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item())
+    # mask dominance: last window of the shifted map mixes regions; make one cross-region logit huge
+    q2, k2, v2 = (rnd(30 + i, s, h * w, C) for i in range(3))
+    idx, label = hp.window_index(h, w, wh, ww, 4, 6)
+    win = idx.shape[0] - 1
+    a = int(idx[win, 0])
+    other = [int(idx[win, j]) for j in range(idx.shape[1]) if label[win, j] != label[win, 0]]
+    assert other
+    q2[0, a] = 0.0
+    q2[0, a, 0] = 60.0
+    k2[0, :, 0] = 0.0
+    k2[0, other[0], 0] = 60.0                   # raw logit 3600/sqrt(128) = 318 > 100 above everything else
+    want = hp.window_attention(q2.double(), k2.double(), v2.double(), h, w, wh, ww, 4, 6)
+    got = ops.window_attention(q2.to(DEV), k2.to(DEV), v2.to(DEV), h, w, wh, ww, 4, 6)
+    assert (want[0, a] - v2[0, other[0]].double()).abs().max() < 1e-6      # the masked key dominates
+    assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_window_attention_properties_at_config2_size(ops, ops_fast):
+    """Size-independent properties at BASELINE config 2's layer size (2B=4 here to bound memory): 64x96 map,
+    2x2 windows of 1536 tokens.  (a) constant v -> same constant; (b) k = 0 -> plain window mean of v,
+    including through the cyclic shift; (c) linearity in v."""
+    s, h, w, wh, ww = 4, 64, 96, 32, 48
+    q = rnd(40, s, h * w, C, scale=2.0).to(DEV)
+    k = rnd(41, s, h * w, C, scale=2.0).to(DEV)
+    v = rnd(42, s, h * w, C).to(DEV)
+    for o in (ops, ops_fast):
+        tol = 1e-5 if o is ops else 2e-2
+        for (sh, sw) in ((0, 0), (16, 24)):
+            const = torch.full_like(v, 0.75)
+            assert (o.window_attention(q, k, const, h, w, wh, ww, sh, sw) - 0.75).abs().max().item() < tol
+    out0 = ops.window_attention(q, torch.zeros_like(k), v, h, w, wh, ww, 0, 0)
+    vm = v.view(s, 2, wh, 2, ww, C).mean(dim=(2, 4), keepdim=True).expand(s, 2, wh, 2, ww, C).reshape(s, h * w, C)
+    assert (out0 - vm).abs().max().item() < 2e-6
+    v2 = rnd(43, s, h * w, C).to(DEV)
+    a = ops.window_attention(q, k, v, h, w, wh, ww, 16, 24)
+    b = ops.window_attention(q, k, v2, h, w, wh, ww, 16, 24)
+    ab = ops.window_attention(q, k, 0.5 * v - 2.0 * v2, h, w, wh, ww, 16, 24)
+    assert (ab - (0.5 * a - 2.0 * b)).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------ global matching / propagation
+@pytest.mark.parametrize('tag', ['soft', 'peaky'])
+def test_global_matching_golden(ops, ops_fast, golden, tag):
+    g = golden('matching')
+    f0, f1 = g[f'{tag}.f0'], g[f'{tag}.f1']
+    b, _, h, w = f0.shape
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    want = hp.global_corr_softmax_flow(f0.double(), f1.double(), True)
+    got = ops.global_corr_softmax_flow(t0, t1, h, w, bidir=True)
+    assert got.shape == (2 * b, 2, h, w)
+    assert err(got, want)[0] < 2e-4, tag                         # feature cells
+    assert err(got, g[f'{tag}.global_flow_bidir'])[0] < 5e-4
+    assert err(ops.global_corr_softmax_flow(t0, t1, h, w), want[:b])[0] < 2e-4
+    want_s = hp.global_corr_softmax_stereo(f0.double(), f1.double())
+    got_s = ops.global_corr_softmax_stereo(t0, t1, h, w)
+    assert got_s.shape == (b, 1, h, w) and err(got_s, want_s)[0] < 1e-4
+    if tag == 'soft':
+        assert err(ops_fast.global_corr_softmax_flow(t0, t1, h, w), want[:b])[1] < 5e-2
+
+
+def test_global_matching_realistic_logits(ops):
+    """Feature statistics of the real random-init model (|f| ~ 4: logits reach +-150, very peaky softmax) at
+    a ragged size (L = 40*56 = 2240, not a multiple of 64 or 128)."""
+    b, h, w = 2, 40, 56
+    f0, f1 = rnd(50, b, C, h, w, scale=4.0), rnd(51, b, C, h, w, scale=4.0)
+    f1 = 0.7 * f0.roll((3, -5), (2, 3)) + 0.3 * f1               # real correspondences
+    want = hp.global_corr_softmax_flow(f0.double(), f1.double(), False)
+    got = ops.global_corr_softmax_flow(tok(f0).to(DEV), tok(f1).to(DEV), h, w)
+    mx, mean = err(got, want)
+    assert mean < 2e-4 and mx < 5e-3, (mx, mean)
+
+
+def test_propagation_golden(ops, golden):
+    g = golden('propagation')
+    proto = UniMatch().feature_flow_attn
+    sd = synth_state_dict({k: v.shape for k, v in proto.state_dict().items()}, seed=11)
+    f0 = g['f0']
+    b, _, h, w = f0.shape
+    x = tok(f0).double()
+    q = x @ sd['q_proj.weight'].double().t() + sd['q_proj.bias'].double()
+    k_glob = q @ sd['k_proj.weight'].double().t() + sd['k_proj.bias'].double()
+    k_loc = x @ sd['k_proj.weight'].double().t() + sd['k_proj.bias'].double()
+    for vch in (2, 1):
+        val = g[f'val{vch}']
+        got = ops.prop_global(q.float().to(DEV), k_glob.float().to(DEV), val.to(DEV), h, w)
+        assert err(got, g[f'global{vch}'])[0] < 2e-4
+        for r in (1, 2):
+            got = ops.prop_local(q.float().to(DEV), k_loc.float().to(DEV), val.to(DEV), h, w, r)
+            assert err(got, g[f'local{vch}_r{r}'])[0] < 2e-4
+
+
+# ------------------------------------------------------------------ local kernels
+@pytest.mark.parametrize('tag', ['soft', 'peaky'])
+def test_local_kernels_golden(ops, golden, tag):
+    g = golden('matching')
+    f0, f1 = g[f'{tag}.f0'], g[f'{tag}.f1']
+    b, _, h, w = f0.shape
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    for r in (4, 2):
+        assert err(ops.local_corr_softmax(t0, t1, h, w, r), g[f'{tag}.local_flow_r{r}'])[0] < 2e-4
+        got = ops.local_corr_with_flow(t0, t1, g[f'{tag}.flow_in'].to(DEV), h, w, r)
+        want = hp.local_corr_with_flow(f0.double(), f1.double(), g[f'{tag}.flow_in'].double(), r)
+        assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item())
+        assert err(got, g[f'{tag}.cost_r{r}'])[0] < 2e-4 * max(1.0, want.abs().max().item())
+    assert err(ops.local_corr_softmax(t0, t1, h, w, 4, one_d=True), g[f'{tag}.stereo_local_r4'])[0] < 2e-4
+    # depth
+    k, pose, cand = g[f'{tag}.K'], g[f'{tag}.pose'], g[f'{tag}.cand']
+    cam = torch.cat([torch.inverse(k).flatten(1), pose[:, :3, :3].flatten(1), pose[:, :3, 3], k.flatten(1)], 1)
+    got = ops.depth_corr_softmax(t0, t1, h, w, cam.contiguous().to(DEV), cand.to(DEV))
+    assert err(got, g[f'{tag}.depth'])[0] < 2e-4
+    got = ops.depth_corr_softmax(t0, t1, h, w, cam.contiguous().to(DEV), cand.to(DEV), from_argmax=True)
+    assert (got.cpu() - g[f'{tag}.depth_argmax']).abs().gt(1e-6).float().mean().item() < 0.01
+
+
+def test_cost_volume_config4_size_properties(ops):
+    """At config-4's scale-1 size (128x192): zero flow -> the centre tap equals the plain per-pixel
+    correlation f0.f1/sqrt(C), and an integer flow only shifts which tap that is (bilinear weights 1,0,0,0)."""
+    b, h, w = 2, 128, 192
+    f0, f1 = rnd(60, b, C, h, w), rnd(61, b, C, h, w)
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    plain = ((f0 * f1).sum(1) / math.sqrt(C)).to(DEV)
+    cost = ops.local_corr_with_flow(t0, t1, torch.zeros(b, 2, h, w, device=DEV), h, w, 4)
+    assert cost.shape == (b, 81, h, w)
+    assert (cost[:, 40] - plain).abs().max().item() < 1e-4
+    flow = torch.zeros(b, 2, h, w, device=DEV)
+    flow[:, 0] = 2.0
+    flow[:, 1] = -1.0
+    cost2 = ops.local_corr_with_flow(t0, t1, flow, h, w, 4)
+    # tap (dy=+1, dx=-2) of the displaced volume looks at p again
+    assert (cost2[:, (1 + 4) * 9 + (-2 + 4)] - plain).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------ end to end through the drop-in module
+SIZES = {'gmflow_s1': (64, 96), 'gmstereo_s1': (64, 96), 'gmdepth_s1': (96, 128), 'gmdepth_s1_rr1': (96, 128),
+         'gmflow_s2_rr6': (128, 192), 'gmstereo_s2_rr3': (128, 192)}
+
+
+def run_product(name, precision='exact', extra=None, batch=1):
+    ck, fk = CONFIGS[name]
+    model = UniMatch(**ck).eval()
+    sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02)
+    model.load_state_dict(sd)
+    model = model.to(DEV).set_precision(precision)
+    hh, ww = SIZES[name]
+    i0, i1 = synth_images(batch, hh, ww, seed=1000, kind='shift', normalized=(fk['task'] != 'flow'))
+    kw = dict(fk)
+    if extra:
+        kw.update(extra)
+    okw = dict(kw)
+    if fk['task'] == 'depth':
+        k, pose = synth_camera(batch, hh, ww)
+        kw.update(intrinsics=k.to(DEV), pose=pose.to(DEV))
+        okw.update(intrinsics=k.double(), pose=pose.double())
+    pred = model(i0.to(DEV), i1.to(DEV), **kw)['flow_preds'][0]
+    okw.update(num_scales=ck['num_scales'], upsample_factor=ck['upsample_factor'], reg_refine=ck['reg_refine'])
+    truth = om.unimatch_forward(sd, i0.double(), i1.double(), **okw)
+    ref32 = om.unimatch_forward(sd, i0, i1, **{k: (v.float() if torch.is_tensor(v) else v) for k, v in okw.items()})
+    return pred.cpu(), truth, ref32
+
+
+@pytest.mark.parametrize('name', sorted(SIZES))
+def test_end_to_end_exact_mode(name, golden):
+    """Whole forward on the GPU vs an fp64 evaluation.  The bar: the HIP path (exact mode) may be at most
+    3x as far from the fp64 truth as the fp32 CPU oracle is (+1e-4 slack); for the well-conditioned
+    single-scale configs that is far below the 1e-3 EPE gate, and the reference's own fp32 output stored in
+    the fixture must be within 1e-3 mean as well."""
+    pred, truth, ref32 = run_product(name)
+    assert pred.shape == truth.shape
+    e_new = (pred.double() - truth).abs().mean().item()
+    e_ref = (ref32.double() - truth).abs().mean().item()
+    assert e_new < 3 * e_ref + 1e-4, (name, e_new, e_ref)
+    if 's2' not in name:
+        g = golden('e2e')
+        assert (pred - g[f'{name}.fp32']).abs().mean().item() < 1e-3
+
+
+def test_end_to_end_bidirectional_and_batch(golden):
+    pred, truth, _ = run_product('gmflow_s1', extra=dict(pred_bidir_flow=True))
+    assert pred.shape == (2, 2, 64, 96)
+    assert (pred.double() - truth).abs().mean().item() < 1e-3
+    assert (pred - golden('e2e')['gmflow_s1_bidir.fp32']).abs().mean().item() < 1e-3
+    pred, truth, _ = run_product('gmdepth_s1', extra=dict(pred_bidir_depth=True))
+    assert (pred.double() - truth).abs().mean().item() < 1e-4
+    pred, truth, _ = run_product('gmflow_s1', batch=3)
+    assert (pred.double() - truth).abs().mean().item() < 1e-3
+
+
+def test_fast_mode_runs_and_is_in_the_ballpark():
+    pred, truth, _ = run_product('gmflow_s1', precision='fast')
+    assert torch.isfinite(pred).all()
+    assert (pred.double() - truth).abs().mean().item() < 2.0     # bf16 operands: px-level, reported not gated

@@ -1,0 +1,176 @@
+"""CPU tests of the product's HOST side: the drop-in boundary (constructor, forward signature, output dict,
+state_dict names), the per-scale orchestration with the oracle injected as hot-path backend, the C-ABI
+library (loads, exports every declared symbol) and the loud failure when no GPU / extension is present."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from unimatch_amd import UniMatch, _abi
+from unimatch_amd.model import attention_windows, sine_position_tokens
+from unimatch_amd.synth import CONFIGS, synth_camera, synth_images, synth_state_dict
+from oracle import hotpath as hp
+from oracle import model as om
+from tests.oracle_ops import OracleOps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = {'gmflow_s1': (64, 96), 'gmstereo_s1': (64, 96), 'gmdepth_s1': (96, 128), 'gmdepth_s1_rr1': (96, 128),
+         'gmflow_s2_rr6': (128, 192), 'gmstereo_s2_rr3': (128, 192)}
+
+
+def build(name, batch=1):
+    ck, fk = CONFIGS[name]
+    model = UniMatch(**ck).eval()
+    sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02)
+    model.load_state_dict(sd)
+    hh, ww = SIZES[name]
+    i0, i1 = synth_images(batch, hh, ww, seed=1000, kind='shift', normalized=(fk['task'] != 'flow'))
+    kw = dict(fk)
+    if fk['task'] == 'depth':
+        k, pose = synth_camera(batch, hh, ww)
+        kw.update(intrinsics=k, pose=pose)
+    return model, sd, i0, i1, kw, ck
+
+
+def oracle_out(sd, i0, i1, kw, ck):
+    okw = dict(kw)
+    okw.update(num_scales=ck['num_scales'], upsample_factor=ck['upsample_factor'], reg_refine=ck['reg_refine'])
+    return om.unimatch_forward(sd, i0, i1, **okw)
+
+
+@pytest.mark.parametrize('name', sorted(SIZES))
+def test_forward_with_injected_oracle_matches_oracle_model(name):
+    """Same maths on both sides (oracle kernels), so any difference is a host-logic bug in the product:
+    layouts, sign flips, clamps, bidirectional concatenation, refinement loop.  fp32 re-association only."""
+    model, sd, i0, i1, kw, ck = build(name)
+    ops = OracleOps()
+    out = model.bind_ops(ops)(i0, i1, **kw)
+    assert list(out.keys()) == ['flow_preds'] and len(out['flow_preds']) == 1
+    pred = out['flow_preds'][0]
+    ref = oracle_out(sd, i0, i1, kw, ck)
+    assert pred.shape == ref.shape
+    tol = 2e-2 if 'rr' in name and 's2' in name else 1e-3       # two-scale refine: ill-conditioned (see synth)
+    assert (pred - ref).abs().mean().item() < tol
+    used = {c[0] for c in ops.calls}
+    assert 'window_attention' in used and len([c for c in ops.calls if c[0] == 'window_attention']) == 12 * ck['num_scales']
+
+
+def test_bidirectional_outputs():
+    model, sd, i0, i1, kw, ck = build('gmflow_s1', batch=2)
+    pred = model.bind_ops(OracleOps())(i0, i1, pred_bidir_flow=True, **kw)['flow_preds'][0]
+    assert pred.shape == (4, 2, 64, 96)
+    ref = oracle_out(sd, i0, i1, dict(kw, pred_bidir_flow=True), ck)
+    assert (pred - ref).abs().mean().item() < 1e-3
+    model, sd, i0, i1, kw, ck = build('gmdepth_s1_rr1', batch=1)
+    pred = model.bind_ops(OracleOps())(i0, i1, pred_bidir_depth=True, **kw)['flow_preds'][0]
+    ref = oracle_out(sd, i0, i1, dict(kw, pred_bidir_depth=True), ck)
+    assert pred.shape == ref.shape == (2, 96, 128)
+    assert (pred - ref).abs().mean().item() < 1e-3
+
+
+def test_signature_matches_reference_boundary():
+    """unimatch/unimatch.py:17-26 and :95-111."""
+    ctor = list(inspect.signature(UniMatch.__init__).parameters)[1:]
+    assert ctor == ['num_scales', 'feature_channels', 'upsample_factor', 'num_head', 'ffn_dim_expansion',
+                    'num_transformer_layers', 'reg_refine', 'task']
+    fwd = inspect.signature(UniMatch.forward).parameters
+    assert list(fwd)[1:] == ['img0', 'img1', 'attn_type', 'attn_splits_list', 'corr_radius_list',
+                             'prop_radius_list', 'num_reg_refine', 'pred_bidir_flow', 'task', 'intrinsics', 'pose',
+                             'min_depth', 'max_depth', 'num_depth_candidates', 'depth_from_argmax',
+                             'pred_bidir_depth', 'kwargs']
+    assert fwd['min_depth'].default == 2.0 and fwd['max_depth'].default == 0.1 and fwd['num_reg_refine'].default == 1
+
+
+def test_state_dict_names_and_param_counts():
+    expected = {'gmflow_s1': 4680288, 'gmflow_s2_rr6': 7360688, 'gmstereo_s2_rr3': 7354416, 'gmdepth_s1_rr1': 7322592}
+    for name, count in expected.items():
+        sd = UniMatch(**CONFIGS[name][0]).state_dict()
+        assert sum(v.numel() for v in sd.values()) == count
+    sd = UniMatch(**CONFIGS['gmflow_s2_rr6'][0]).state_dict()
+    for key in ('backbone.conv1.weight', 'backbone.layer2.0.downsample.0.bias', 'backbone.trident_conv.weight',
+                'transformer.layers.5.cross_attn_ffn.mlp.2.weight', 'transformer.layers.0.self_attn.norm1.bias',
+                'feature_flow_attn.k_proj.bias', 'refine_proj.weight', 'refine.encoder.convc1.weight',
+                'refine.gru.convq2.bias', 'refine.flow_head.conv2.weight', 'refine.mask.2.weight'):
+        assert key in sd, key
+    assert 'upsampler.0.weight' in UniMatch().state_dict()
+    assert 'upsampler.0.weight' not in sd
+
+
+def test_reference_error_behaviour():
+    model, sd, i0, i1, kw, ck = build('gmflow_s1')
+    model.bind_ops(OracleOps())
+    with pytest.raises(AssertionError):                         # list lengths must equal num_scales
+        model(i0, i1, **dict(kw, attn_splits_list=[2, 8]))
+    with pytest.raises(AssertionError):                         # bidirectional flow is a flow-only feature
+        model(i0, i1, **dict(kw, task='stereo', pred_bidir_flow=True))
+    with pytest.raises(NotImplementedError):
+        UniMatch(num_head=2)
+    with pytest.raises(RuntimeError):                           # inference only
+        UniMatch().train()(i0, i1, **kw)
+    with pytest.raises(AssertionError):                         # map not divisible by the splits
+        model(i0, i1, **dict(kw, attn_splits_list=[5]))
+
+
+def test_attention_windows_agree_with_oracle_dispatch():
+    for attn_type in ('swin', 'self_swin2d_cross_1d', 'self_swin2d_cross_swin1d', 'other'):
+        for splits in (1, 2, 4):
+            for is_self in (True, False):
+                for shift in (True, False):
+                    assert attention_windows(attn_type, is_self, splits, 8, 16, shift) == \
+                        hp.attention_geometry(attn_type, is_self, splits, 8, 16, shift)
+
+
+def test_position_tokens_bit_exact(golden):
+    g = golden('position')
+    tab = sine_position_tokens(4, 6, 2, 2, 128)                 # [8*12, 128] tokens
+    f0 = g['f0']
+    want = g['add_k2_0'] - f0                                    # not exact (a+b-a), compare the sum instead
+    got = f0 + tab.t().reshape(1, 128, 8, 12)
+    assert torch.equal(got, g['add_k2_0'])
+    assert want.shape == (2, 128, 8, 12)
+
+
+# ------------------------------------------------------------------ the C-ABI library
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'unimatch_hip.h')).read()
+    return sorted(set(re.findall(r'\b(um_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_abi.LIB_PATH), 'build it with python -m unimatch_amd.build'
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_abi.SIGNATURES) == names                     # the ctypes table mirrors the header
+    assert _abi.load().um_version() == 100
+
+
+def test_abi_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it can be exercised on a GPU-less host."""
+    lib = _abi.load()
+    assert lib.um_window_attn_workspace_bytes(2, 96, 64, 0) == 0            # unsupported channel count
+    assert lib.um_window_attn_workspace_bytes(2, 96, 128, 0) == 3 * 2 * 96 * 128 * 2 * 2
+    assert lib.um_window_attn_workspace_bytes(2, 96, 128, 1) == 3 * 2 * 96 * 128 * 2
+    rc = lib.um_window_attn_fwd(None, None, None, None, 1, 8, 12, 128, 4, 6, 0, 0, 0, None, 0, None)
+    assert rc == -1 and b'null' in lib.um_last_error_string()
+    fake = ctypes.c_void_p(4096)
+    rc = lib.um_window_attn_fwd(fake, fake, fake, fake, 1, 8, 12, 128, 3, 6, 0, 0, 0, None, 0, None)
+    assert rc == -2 and b'does not tile' in lib.um_last_error_string()
+    rc = lib.um_window_attn_fwd(fake, fake, fake, fake, 1, 8, 12, 128, 4, 6, 4, 0, 0, None, 0, None)
+    assert rc == -2
+    rc = lib.um_window_attn_fwd(fake, fake, fake, fake, 1, 8, 12, 128, 4, 6, 2, 3, 0, None, 0, None)
+    assert rc == -3 and b'workspace' in lib.um_last_error_string()
+    rc = lib.um_local_corr_softmax(fake, fake, fake, 1, 8, 12, 128, 40, 0, None)
+    assert rc == -4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the GPU-less failure mode')
+def test_hot_path_fails_loudly_without_gpu():
+    model, sd, i0, i1, kw, ck = build('gmflow_s1')
+    with pytest.raises(_abi.HipExtensionError):
+        model(i0, i1, **kw)

@@ -1,8 +1,12 @@
-// Library-wide pieces of the C ABI: version and the per-thread error string.
+// Library-wide pieces of the C ABI: version, per-thread error string, optional HIP-event kernel timing.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "../../include/unimatch_hip.h"
+#include "timing.h"
 
 static thread_local char g_err[512] = "";
 
@@ -16,3 +20,71 @@ void um_set_error(const char* fmt, ...) {
 extern "C" int um_version(void) { return UM_VERSION; }
 
 extern "C" const char* um_last_error_string(void) { return g_err; }
+
+// ---- timing: hipEvents recorded on the launch stream right around a kernel, read back on demand ----------
+namespace {
+struct TimingState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> live[UM_K_COUNT];
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+TimingState g_t;
+}  // namespace
+
+bool um_timing_on() { return g_t.on; }
+
+void* um_timing_begin(int kid, hipStream_t stream) {
+    if (!g_t.on || kid < 0 || kid >= UM_K_COUNT) return nullptr;
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    hipEvent_t a = g_t.get(), b = g_t.get();
+    if (!a || !b) return nullptr;
+    (void)hipEventRecord(a, stream);
+    g_t.live[kid].push_back({a, b});
+    return (void*)b;
+}
+
+void um_timing_end(void* token, hipStream_t stream) {
+    if (token) (void)hipEventRecord((hipEvent_t)token, stream);
+}
+
+extern "C" int um_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    g_t.on = on != 0;
+    return 0;
+}
+
+extern "C" int um_timing_collect(int kernel_id, double* total_ms, int* launches) {
+    if (kernel_id < 0 || kernel_id >= UM_K_COUNT || !total_ms || !launches) {
+        um_set_error("um_timing_collect: bad kernel id %d or null output", kernel_id);
+        return UM_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    double sum = 0.0;
+    int n = 0;
+    for (auto& pr : g_t.live[kernel_id]) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (e == hipSuccess) {
+            sum += ms;
+            ++n;
+        }
+        g_t.pool.push_back(pr.first);
+        g_t.pool.push_back(pr.second);
+    }
+    g_t.live[kernel_id].clear();
+    *total_ms = sum;
+    *launches = n;
+    return 0;
+}

@@ -204,6 +204,7 @@ extern void um_set_error(const char* fmt, ...);
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(const GsvArgs& a, int nbatch, int mode, hipStream_t stream) {
     dim3 grid((a.Lq + 127) / 128, nbatch), block(256);
+    ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
     if (mode == 0)
         hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
     else

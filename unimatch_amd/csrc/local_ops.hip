@@ -16,6 +16,7 @@
 // shuffles.  Taps are processed 16 per round.  Softmax statistics are reduced across the 16 slots with
 // four more shuffles.  Token-major feature layout [B, L, 128] fp32.
 #include "common.h"
+#include "timing.h"
 
 #define LOCAL_MAX_ROUNDS 8      // up to 128 taps / depth candidates
 
@@ -402,6 +403,7 @@ extern "C" int um_local_corr_softmax(const float* f0, const float* f1, float* ou
         um_set_error("radius=%d unsupported (at most %d taps)", radius, 16 * LOCAL_MAX_ROUNDS);
         return -4;
     }
+    ScopedKernelTimer timer(UM_K_LOCAL_CORR, (hipStream_t)stream);
     hipLaunchKernelGGL(local_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
                        (hipStream_t)stream, f0, f1, out, batch, h, w, radius, one_d);
     return (int)hipGetLastError();
@@ -419,6 +421,7 @@ extern "C" int um_local_corr_with_flow(const float* f0, const float* f1, const f
         return -4;
     }
     const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
+    ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
     hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0,
                        (hipStream_t)stream, f0, f1, flow, cost, batch, h, w, radius);
     return (int)hipGetLastError();
@@ -435,6 +438,7 @@ extern "C" int um_prop_local_attn(const float* q, const float* k, const float* v
         um_set_error("radius=%d unsupported (at most %d taps)", radius, 16 * LOCAL_MAX_ROUNDS);
         return -4;
     }
+    ScopedKernelTimer timer(UM_K_PROP_LOCAL, (hipStream_t)stream);
     hipLaunchKernelGGL(prop_local_attn_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
                        (hipStream_t)stream, q, k, value, out, batch, h, w, value_channels, radius);
     return (int)hipGetLastError();
@@ -448,6 +452,7 @@ extern "C" int um_depth_corr_softmax(const float* f0, const float* f1, const flo
         um_set_error("num_candidates=%d unsupported (1..%d)", num_candidates, 16 * LOCAL_MAX_ROUNDS);
         return -4;
     }
+    ScopedKernelTimer timer(UM_K_DEPTH_CORR, (hipStream_t)stream);
     hipLaunchKernelGGL(depth_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
                        (hipStream_t)stream, f0, f1, cam, candidates, out, batch, h, w, num_candidates, from_argmax);
     return (int)hipGetLastError();

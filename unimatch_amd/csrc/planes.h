@@ -4,6 +4,7 @@
 // Plane layout: [NS][rows][128] 16-bit, plane stride = rows*128 elements.
 #pragma once
 #include "common.h"
+#include "timing.h"
 
 template <class T, int NS>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src,
@@ -42,6 +43,7 @@ static inline hipError_t launch_split_planes(const float* src, unsigned short* d
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     const long plane_stride = rows * UM_CHANNELS;
+    ScopedKernelTimer timer(UM_K_SPLIT_PLANES, stream);
     if (mode == 0)
         hipLaunchKernelGGL((split_planes_kernel<Fp16, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n8,
                            scale, plane_stride);

@@ -347,6 +347,7 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
     a.total = a.nqt * a.nwin * streams;
     a.scale_log2 = UM_LOG2E / sqrtf((float)channels);
     a.mask_raw = -100.0f * sqrtf((float)channels);
+    ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (mode == 0)
         hipLaunchKernelGGL((window_attn_kernel<Fp16, 2>), dim3(a.total), dim3(256), 0, stream, a);
     else

@@ -250,6 +250,9 @@ class UniMatch(nn.Module):
         return self._ops
 
     def _position(self, h, w, splits, device):
+        # same precondition as the reference's split_feature (unimatch/utils.py:40)
+        assert splits <= 1 or (h % splits == 0 and w % splits == 0), \
+            f'feature map {h}x{w} is not divisible by attn_splits={splits}'
         key = (h, w, splits, str(device))
         if key not in self._pos_cache:
             if splits > 1:
