@@ -147,25 +147,44 @@ def main():
 
     # ---- CPU baseline: the pinned port of the reference, bounded sample, same workload shape
     cpu = None
-    epe = None
+    epe = {}
     if not args.no_cpu_baseline:
         from oracle import model as om
-        ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         c0, c1 = i0[:1].cpu(), i1[:1].cpu()
         okw = dict(fk, num_scales=ck['num_scales'], upsample_factor=ck['upsample_factor'], reg_refine=ck['reg_refine'])
-        ref = om.unimatch_forward(sd, c0, c1, **okw)                 # warm-up + parity sample
+        ncores = os.cpu_count() or 1
+        # torch's CPU ops stop scaling (and then collapse) long before 256 threads: pick the fastest of a
+        # short sweep, then time the bounded sample with it and report the thread count actually used
+        best_t, best_s, ref = None, None, None
+        for threads in [t for t in (8, 16, 32, 64) if t <= ncores] or [ncores]:
+            torch.set_num_threads(threads)
+            if ref is None:
+                ref = om.unimatch_forward(sd, c0, c1, **okw)         # warm-up + fp32 parity sample
+            t1 = time.perf_counter()
+            om.unimatch_forward(sd, c0, c1, **okw)
+            dt = time.perf_counter() - t1
+            if best_s is None or dt < best_s:
+                best_t, best_s = threads, dt
+        torch.set_num_threads(best_t)
         t1 = time.perf_counter()
         iters = 0
-        while iters < args.cpu_iters and (time.perf_counter() - t1) < 30.0:
+        while iters < args.cpu_iters and (time.perf_counter() - t1) < 25.0:
             om.unimatch_forward(sd, c0, c1, **okw)
             iters += 1
         cpu_s = (time.perf_counter() - t1) / max(iters, 1)
-        cpu = {'value': round(1.0 / cpu_s, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': f'{iters} forwards of 1 pair {HEIGHT}x{WIDTH} (fp32 torch-CPU port of the reference), '
-                         f'{cpu_s:.2f} s each'}
-        d = (pred[:1].cpu() - ref)
-        epe = d.pow(2).sum(1).sqrt().mean().item()
+        cpu = {'value': round(1.0 / cpu_s, 4), 'unit': 'pairs/s', 'cores': best_t, 'kind': 'port',
+               'host_cores': ncores,
+               'sample': f'{iters} forwards of 1 pair {HEIGHT}x{WIDTH} (fp32 torch-CPU port of the reference, '
+                         f'pinned to it by tests/golden), {cpu_s:.2f} s each'}
+        truth = om.unimatch_forward(sd, c0.double(), c1.double(), **okw)     # fp64 evaluation = ground truth
+
+        def _epe(a, b_):
+            return (a.double() - b_.double()).pow(2).sum(1).sqrt().mean().item()
+        g = pred[:1].cpu()
+        epe = {'gpu_vs_fp64_truth': round(_epe(g, truth), 6), 'cpu_fp32_vs_fp64_truth': round(_epe(ref, truth), 6),
+               'gpu_vs_cpu_fp32': round(_epe(g, ref), 6),
+               'note': 'mean end-point error in pixels at full resolution on 1 sample pair; the middle figure is '
+                       'the fp32 reference-port noise floor at random-init weights'}
 
     pairs = world * b * args.steps
     value = pairs / elapsed
@@ -183,7 +202,7 @@ def main():
                    'parallelism': f'dp{world} (batch-sharded, all-gather of predictions)' if distributed else 'single GPU'},
         'roofline': roof, 'roofline_global_corr': roof2,
         'split_planes_ms_per_step': round(split_ms / args.steps, 3) if split_n else None,
-        'cpu_baseline': cpu, 'epe_vs_cpu_port_fp32': None if epe is None else round(epe, 6),
+        'cpu_baseline': cpu, 'epe': epe or None,
         'speedup_vs_cpu_port': None if cpu is None else round(value / cpu['value'], 1),
     }
     print(json.dumps(line))

@@ -141,6 +141,8 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
         if pred_bidir_flow and s > 0:
             f0, f1 = torch.cat([f0, f1], 0), torch.cat([f1, f0], 0)
         f0_ori, f1_ori = f0, f1
+        if taps is not None:
+            taps[f'backbone0_s{s}'], taps[f'backbone1_s{s}'] = f0, f1
         up = upsample_factor * 2 ** (num_scales - 1 - s)
         if task == 'depth':
             k_cur = intrinsics.to(dt).clone()

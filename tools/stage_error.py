@@ -1,0 +1,40 @@
+"""Diagnostic (GPU box): per-stage error of the product forward against an fp64 evaluation of the oracle,
+next to the fp32 CPU oracle's own error -- shows which stage (MIOpen convs, hipBLASLt linears, HIP kernels)
+adds noise beyond the fp32 floor.   python tools/stage_error.py [H W]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import model as om  # noqa: E402
+from unimatch_amd import UniMatch  # noqa: E402
+from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict  # noqa: E402
+
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (512, 768)
+torch.set_num_threads(min(32, os.cpu_count() or 8))
+ck, fk = CONFIGS['gmflow_s1']
+model = UniMatch(**ck).eval()
+sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()})
+model.load_state_dict(sd)
+model = model.cuda()
+i0, i1 = synth_images(1, H, W, seed=1000, kind='shift')
+kw = dict(fk, num_scales=1, upsample_factor=8, reg_refine=False)
+t32, t64, tg = {}, {}, {}
+o32 = om.unimatch_forward(sd, i0, i1, taps=t32, **kw)
+o64 = om.unimatch_forward(sd, i0.double(), i1.double(), taps=t64, **kw)
+for prec in ('exact', 'fast'):
+    model.set_precision(prec)
+    model.debug_taps = tg = {}
+    og = model(i0.cuda(), i1.cuda(), **fk)['flow_preds'][0].cpu()
+    print(f'--- precision={prec}  {H}x{W}')
+    for k in t64:
+        if k not in tg:
+            continue
+        dg = (tg[k].cpu().double() - t64[k]).abs()
+        dc = (t32[k].double() - t64[k]).abs()
+        print(f'{k:16s} |x| {t64[k].abs().mean():8.3f}   GPU-vs-fp64 mean {dg.mean():.2e} max {dg.max():.2e}   '
+              f'CPUfp32-vs-fp64 mean {dc.mean():.2e} max {dc.max():.2e}')
+    epe = lambda a, b: (a.double() - b.double()).pow(2).sum(1).sqrt().mean().item()
+    print(f'final EPE: GPU vs fp64 {epe(og, o64):.3e}   CPU fp32 vs fp64 {epe(o32, o64):.3e}   GPU vs CPU fp32 {epe(og, o32):.3e}')

@@ -229,6 +229,7 @@ class UniMatch(nn.Module):
         self._ops = None
         self._precision = 'exact'
         self._pos_cache = {}
+        self.debug_taps = None            # set to a dict to collect named intermediates (diagnostics only)
 
     # ------------------------------------------------------------------ hot-path backend
     def set_precision(self, precision):
@@ -313,7 +314,11 @@ class UniMatch(nn.Module):
                 splits, prop_r = attn_splits_list[s], prop_radius_list[s]
                 pos = self._position(h, w, splits, dev)
                 tok0, tok1 = ori0 + pos, tok1 + pos
+                if self.debug_taps is not None:
+                    self.debug_taps[f'backbone0_s{s}'], self.debug_taps[f'backbone1_s{s}'] = m0, m1
                 tok0, tok1 = self.transformer(ops, tok0, tok1, h, w, attn_type, splits)
+                if self.debug_taps is not None:
+                    self.debug_taps[f'f0_s{s}'], self.debug_taps[f'f1_s{s}'] = _to_map(tok0, h, w), _to_map(tok1, h, w)
 
                 # ---- matching layer
                 if task == 'depth':
@@ -342,12 +347,16 @@ class UniMatch(nn.Module):
                 flow = flow_pred if flow is None else flow + flow_pred
                 if task == 'stereo':
                     flow = flow.clamp(min=0)
+                if self.debug_taps is not None:
+                    self.debug_taps[f'flow_match_s{s}'] = flow
 
                 # ---- propagation
                 if (pred_bidir_flow or pred_bidir_depth) and s == 0:
                     tok0 = torch.cat([tok0, tok1], 0)
                 flow = self.feature_flow_attn(ops, tok0, flow.contiguous(), h, w,
                                               local_window_attn=prop_r > 0, local_window_radius=prop_r)
+                if self.debug_taps is not None:
+                    self.debug_taps[f'flow_prop_s{s}'] = flow
                 if s < self.num_scales - 1:
                     continue
 
