@@ -1,0 +1,101 @@
+"""Micro-benchmark of the HIP entry points at BASELINE sizes (GPU box).  Kernel time comes from the library's
+own hipEvents (um_timing_*), so split/convert pre-passes are reported separately from the main kernels.
+
+    python tools/bench_ops.py [attn] [gsv] [local] [--iters N] [--precision exact|fast] [--quick]
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from unimatch_amd import _abi  # noqa: E402
+from unimatch_amd.ops import HipOps  # noqa: E402
+
+KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr']
+PEAK = 2.5e15
+
+
+def collect(lib):
+    out = {}
+    for kid, name in enumerate(KNAMES):
+        ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        lib.um_timing_collect(kid, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            out[name] = (ms.value / n.value, n.value)
+    return out
+
+
+def run(label, fn, flops, lib, iters, kernel, issued=1.0):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    lib.um_timing_enable(1)
+    collect(lib)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    lib.um_timing_enable(0)
+    t = collect(lib)
+    ms = t[kernel][0]
+    extra = ' '.join(f'{k}={v[0] * v[1] / iters:.3f}ms' for k, v in t.items() if k != kernel)
+    tf = flops / (ms * 1e-3) / 1e12
+    print(f'{label:46s} {ms:8.4f} ms  {tf:8.1f} TF/s alg ({100 * tf * 1e12 / PEAK:5.2f}% peak, issued {100 * tf * issued * 1e12 / PEAK:5.2f}%)  [{extra}]',
+          flush=True)
+
+
+def main():
+    args = sys.argv[1:]
+    iters = int(args[args.index('--iters') + 1]) if '--iters' in args else 10
+    prec = args[args.index('--precision') + 1] if '--precision' in args else 'exact'
+    what = [a for a in args if a in ('attn', 'gsv', 'local')] or ['attn', 'gsv', 'local']
+    ops = HipOps(prec)
+    lib = _abi.load()
+    issued = 3.0 if prec == 'exact' else 1.0
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(0)
+    C = 128
+    if 'attn' in what:
+        # config 2: 2B = 16 streams, 64x96 map, 2x2 windows of 32x48 = 1536 tokens
+        S, h, w = 16, 64, 96
+        q, k, v = (torch.randn(S, h * w, C, device=dev, generator=g) * 2 for _ in range(3))
+        for sh, sw, tag in ((0, 0, 'plain'), (16, 24, 'shifted')):
+            run(f'attn cfg2 S=16 64x96 win32x48 {tag}', lambda: ops.window_attention(q, k, v, h, w, 32, 48, sh, sw),
+                4.0 * S * h * w * 1536 * C, lib, iters, 'window_attn', issued)
+        if '--quick' not in args:
+            # config 4 scale 1 (4 pairs/GPU): 8 streams, 128x192 map, 8x8 windows of 16x24 = 384 tokens
+            S, h, w = 8, 128, 192
+            q, k, v = (torch.randn(S, h * w, C, device=dev, generator=g) * 2 for _ in range(3))
+            run('attn cfg4-s1 S=8 128x192 win16x24 shifted', lambda: ops.window_attention(q, k, v, h, w, 16, 24, 8, 12),
+                4.0 * S * h * w * 384 * C, lib, iters, 'window_attn', issued)
+            # config 3 scale 1 cross attention: 1-D windows of 30 on 128x240
+            S, h, w = 8, 128, 240
+            q, k, v = (torch.randn(S, h * w, C, device=dev, generator=g) * 2 for _ in range(3))
+            run('attn cfg3-s1 S=8 128x240 1-D win30 shifted', lambda: ops.window_attention(q, k, v, h, w, 1, 30, 0, 15),
+                4.0 * S * h * w * 30 * C, lib, iters, 'window_attn', issued)
+    if 'gsv' in what:
+        B, h, w = 8, 64, 96
+        L = h * w
+        f0, f1 = (torch.randn(B, L, C, device=dev, generator=g) * 3 for _ in range(2))
+        run('global corr flow cfg2 B=8 L=6144', lambda: ops.global_corr_softmax_flow(f0, f1, h, w),
+            B * (2.0 * L * L * C + 4.0 * L * L), lib, iters, 'gsv', issued)
+        val = torch.randn(B, 2, h, w, device=dev, generator=g)
+        run('global propagation cfg2 B=8 L=6144', lambda: ops.prop_global(f0, f1, val, h, w),
+            B * (2.0 * L * L * C + 4.0 * L * L), lib, iters, 'gsv', issued)
+    if 'local' in what:
+        B, h, w = 4, 128, 192
+        L = h * w
+        f0, f1 = (torch.randn(B, L, C, device=dev, generator=g) for _ in range(2))
+        flow = torch.randn(B, 2, h, w, device=dev, generator=g) * 3
+        run('cost volume cfg4 B=4 128x192 r=4', lambda: ops.local_corr_with_flow(f0, f1, flow, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume')
+        run('local corr softmax cfg4 B=4 128x192 r=4', lambda: ops.local_corr_softmax(f0, f1, h, w, 4),
+            2.0 * B * L * 81 * C, lib, iters, 'local_corr')
+        run('prop local cfg4 B=4 128x192 r=1', lambda: ops.prop_local(f0, f1, flow, h, w, 1),
+            2.0 * B * L * 9 * C, lib, iters, 'prop_local')
+
+
+if __name__ == '__main__':
+    main()

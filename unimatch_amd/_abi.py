@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libunimatch_hip.so')
+LIB_PATH = os.environ.get('UM_LIB') or os.path.join(_HERE, 'libunimatch_hip.so')   # UM_LIB: diagnostics builds only
 
 MODE_EXACT = 0
 MODE_FAST = 1

@@ -85,6 +85,23 @@ __device__ __forceinline__ i16x8 ld_global_16B(const unsigned short* p) {
     return *reinterpret_cast<const i16x8*>(p);
 }
 
+// Exchange between the two half-waves without LDS: returns, on every lane, {own value, value of lane ^ 32} in
+// some order.  v_permlane32_swap swaps the upper half of one register with the lower half of another.
+// Two hipcc (ROCm 7.2) pitfalls are handled here, both found the hard way:
+//   * symmetric uses of the two results -- fmaxf(r0, r1), r0 + r1 -- are folded as if r0 == r1 (the combine
+//     looks at the producing node, not at the result index): each result is laundered through an empty asm;
+//   * hipcc's hazard recognizer does not look through an inline-asm statement, so the 2 wait states the swap
+//     needs after a VALU write of its operands are supplied explicitly.
+__device__ __forceinline__ void half_wave_pair(float v, float& a, float& b) {
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm volatile("s_nop 1" : "+v"(y), "+v"(x));
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    unsigned r0 = sw[0], r1 = sw[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+
 // XCD-aware remap of a linear workgroup id: the dispatcher places consecutive ids on consecutive
 // XCDs (id % 8); this gives every XCD a contiguous range of logical ids so that workgroups sharing
 // K/V (query tiles of one window) hit the same L2.  Bijective for any total.  Speed only.

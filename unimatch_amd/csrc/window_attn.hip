@@ -11,9 +11,9 @@
 //   * scores and probabilities never leave registers (the reference materialises [2B*K^2, n, n] fp32 scores
 //     plus a repeated mask: 2 x 604 MB per layer at B=8, 512x768).
 //
-// Decomposition: workgroup = 4 waves = 128 query tokens of one window; wave = 32 queries; K/V tiles of 64
-// window tokens staged through LDS.  Two workgroups share a CU (76 KB LDS each in exact mode) so one
-// workgroup's staging overlaps the other's MFMAs.  Everything is computed transposed so that the MFMA
+// Decomposition: workgroup = 4 waves = 128 query tokens of one window; wave = 32 queries; K/V tiles of 32
+// window tokens stream into a 2-deep LDS ring by LDS-DMA (global_load_lds, no staging registers) while the
+// previous tile is consumed; one barrier per tile.  Two workgroups share a CU (65 KB LDS each in exact mode).  Everything is computed transposed so that the MFMA
 // column index n is the query: lane l owns query (l & 31) in BOTH products,
 //       S^T = K . Q^T      (A = K rows from LDS via ds_read_b128,            B = Q^T held in registers)
 //       O^T = V^T . P^T    (A = V^T via ds_read_b64_tr_b16 transpose reads,  B = P^T built in registers)
@@ -22,8 +22,23 @@
 //
 // Precision (mode): exact = fp16 hi+lo operands, 3 MFMA products per contraction (lo*hi, hi*lo, hi*hi),
 // probabilities scaled by 2^14 before the fp16 split so that small p keep 22 bits; fast = bf16, 1 product.
+#include <type_traits>
 #include "common.h"
 #include "planes.h"
+
+// Diagnostic ablations (tools/ablate_attn.sh builds variant libraries with -DUM_ABL=<bits>; never set in the product build)
+//   1 no exp/convert (softmax VALU)   2 no PV MFMAs   4 no QK MFMAs   8 no LDS-DMA in the loop   16 no barrier in the loop
+#ifndef UM_ABL
+#define UM_ABL 0
+#endif
+// -DUM_TRACE: wave 0 / lane 0 of every 37th workgroup stamps s_memtime at section boundaries of its first 24 tiles
+// into the buffer given to um_debug_set_trace() (diagnostics only; tools/trace_attn.py).
+#ifdef UM_TRACE
+__device__ unsigned long long* g_um_trace = nullptr;
+#define UM_STAMP(slot) do { if (tracing && t < 24) trace_buf[(t) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UM_STAMP(slot) do { } while (0)
+#endif
 
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
@@ -40,30 +55,50 @@ struct WattnArgs {
     float mask_raw;              // -100 * sqrt(C): the shifted-window mask in raw q.k units
 };
 
-// window-local token -> global token index (and its shifted-window region label)
-__device__ __forceinline__ int window_token(const WattnArgs& a, int wy, int wx, int t, int& label) {
+// window-local token -> global token index and its mask class.
+// Class = 2*[rolled row in the wrapped band] + [rolled col in the wrapped band].  Inside ONE window this is
+// equivalent to the reference's 3x3 region label (unimatch/utils.py:90-100): two tokens of a window carry
+// different labels iff their classes differ (the first label band never shares a window with the others).
+__device__ __forceinline__ int window_token(const WattnArgs& a, int wy, int wx, int t, int& cls) {
     const int ly = t / a.win_w, lx = t - ly * a.win_w;
     const int ry = wy * a.win_h + ly, rx = wx * a.win_w + lx;
     int oy = ry + a.shift_h, ox = rx + a.shift_w;
     oy = oy >= a.h ? oy - a.h : oy;
     ox = ox >= a.w ? ox - a.w : ox;
-    const int rl = a.shift_h > 0 ? (int)(ry >= a.h - a.win_h) + (int)(ry >= a.h - a.shift_h) : 0;
-    const int cl = a.shift_w > 0 ? (int)(rx >= a.w - a.win_w) + (int)(rx >= a.w - a.shift_w) : 0;
-    label = 3 * rl + cl;
+    const int rb = (a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0;
+    const int cb = (a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0;
+    cls = 2 * rb + cb;
     return oy * a.w + ox;
 }
 
-template <class T, int NS>
-__global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
-    constexpr int KROW = 272;                 // K rows: 256 B + 16 B pad  (ds_read_b128 conflict free)
-    constexpr int VROW = 320;                 // V rows: 256 B + 64 B pad  (4 consecutive keys -> 4 bank quarters)
-    constexpr int KPLANE = 64 * KROW, VPLANE = 64 * VROW;
-    constexpr int PSHIFT = (NS == 2) ? 14 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * (KPLANE + VPLANE) + 64];
-    unsigned char* ldsV = lds + NS * KPLANE;
-    unsigned char* klab = lds + NS * (KPLANE + VPLANE);
+// 16 bytes per lane, global -> LDS without passing through VGPRs: LDS address = wave-uniform dst + 16 * lane.
+// Issued through inline asm on purpose: hipcc cannot prove that the ring slot being filled and the slot being
+// read do not alias and would drain the DMA (s_waitcnt vmcnt(0)) in front of the first LDS read; hidden from its
+// scoreboard, the transfer stays in flight for the whole tile and is waited for explicitly before the barrier.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <class T, int NS>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
+    // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
+    // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
+    // table [4 query classes][TK].  Two buffers: tile t+1 streams in by LDS-DMA while tile t is consumed.
+    constexpr int TK = 32;
+    constexpr int PLANE = TK * 256;
+    constexpr int BIAS_OFF = 2 * NS * PLANE;
+    constexpr int BUF = BIAS_OFF + 4 * TK * 4;
+    constexpr int PSHIFT = (NS == 2) ? 14 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int wg = xcd_remap(blockIdx.x, a.total);
     const int qt = wg % a.nqt;
@@ -76,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
 
     // ---- this lane's query -----------------------------------------------------------------------
     const int tq = qt * 128 + wave * 32 + (lane & 31);
-    int labq;
-    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), labq);
+    int clsq;
+    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
     i16x8 qf[NS][8];
     {
         const unsigned short* qb = a.qp + (sbase + tokq) * UM_CHANNELS + 8 * half;
@@ -85,6 +120,12 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
         for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.plane_stride + 16 * ks);
+        // Make hipcc retire these loads HERE: inside the tile loop its scoreboard must be empty, otherwise its
+        // counted vmcnt(N) waits for them would also wait for the (uncounted) LDS-DMA issued by inline asm.
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
     }
 
     f32x16 o[4];
@@ -94,93 +135,189 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
 
-    const int ntiles = (a.n + 63) >> 6;
-    // per-lane LDS bases
-    const unsigned char* kb = lds + (lane & 31) * KROW + half * 16;
+    const int ntiles = (a.n + TK - 1) / TK;
+#ifdef UM_TRACE
+    const bool tracing = g_um_trace != nullptr && (blockIdx.x % 37) == 0 && tid == 0;
+    unsigned long long* trace_buf = g_um_trace + (size_t)(blockIdx.x / 37) * (24 * 8 + 8);
+    if (tracing) trace_buf[24 * 8] = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
+    // 8w..8w+7 of the tile (2 instructions per plane).  LDS chunk position cp of row r holds source chunk
+    // cp ^ swz(r): swzK = r & 15 (A-fragment ds_read_b128 conflict free), swzV = (r & 3) << 2 (the 4 rows of a
+    // ds_read_b64_tr_b16 group land in 4 different bank quarters).
+    // The kernel is instruction-issue bound (rocprof + ablations, profiles/), so the per-tile addressing is kept
+    // division free: every lane carries the window-local (ly, lx) of the rows it stages and advances them by
+    // TK tokens per tile with one add / compare / select each.
+    const int adv_y = TK / a.win_w, adv_x = TK - adv_y * a.win_w;      // TK tokens = adv_y rows + adv_x columns
+    const int y0 = wy * a.win_h, x0 = wx * a.win_w;
+    int sly[2], slx[2];                                                  // staged rows (j = 0, 1)
+    long ssrc_k[2], ssrc_v[2];                                           // lane-constant part of the source offsets
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 8 * wave + 4 * j + ((lane >> 4) & 3);
+        sly[j] = row / a.win_w;
+        slx[j] = row - sly[j] * a.win_w;
+        const int cp = lane & 15;
+        ssrc_k[j] = (cp ^ (row & 15)) << 3;
+        ssrc_v[j] = (cp ^ ((row & 3) << 2)) << 3;
+    }
+    int bly = 0, blx = 0;                                                // bias-table key of this thread (tid < 4*TK)
+    {
+        const int key = tid & (TK - 1);
+        bly = key / a.win_w;
+        blx = key - bly * a.win_w;
+    }
+    auto token_at = [&](int ly, int lx, int& cls) -> int {             // (ly, lx) may run past the window: clamp
+        ly = min(ly, a.win_h - 1);
+        const int ry = y0 + ly, rx = x0 + lx;
+        int oy = ry + a.shift_h, ox = rx + a.shift_w;
+        oy = oy >= a.h ? oy - a.h : oy;
+        ox = ox >= a.w ? ox - a.w : ox;
+        cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
+        return oy * a.w + ox;
+    };
+    auto advance = [&](int& ly, int& lx) {
+        lx += adv_x;
+        ly += adv_y;
+        const bool wrap = lx >= a.win_w;
+        lx = wrap ? lx - a.win_w : lx;
+        ly = wrap ? ly + 1 : ly;
+    };
+    // Staging of tile t is split in two: prepare (source addresses of this lane's two rows, bias table) and
+    // NPIECE single-instruction DMA pieces.  All waves leave the barrier together, and a burst of 8 DMA
+    // instructions per wave queues up in the CU's single address unit (measured: ~1100 of ~5400 cycles per
+    // tile); issued one per k-step of the QK^T loop instead, each piece hides under three MFMAs.
+    constexpr int NPIECE = 4 * NS;
+    const unsigned short* spk[2];
+    const unsigned short* spv[2];
+    auto stage_prepare = [&](int t, unsigned char* base) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int cls;
+            const int tok = token_at(sly[j], slx[j], cls);
+            advance(sly[j], slx[j]);
+            const long goff = (sbase + tok) * UM_CHANNELS;
+            spk[j] = a.kp + goff + ssrc_k[j];
+            spv[j] = a.vp + goff + ssrc_v[j];
+        }
+        // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
+        const bool need = has_mask || (t + 1) * TK > a.n;
+        if (need && tid < 4 * TK) {
+            const int cq = tid >> 5, key = tid & (TK - 1);
+            int cls;
+            (void)token_at(bly, blx, cls);
+            const float bv = t * TK + key >= a.n ? UM_NEG_MASK : ((has_mask && cls != cq) ? a.mask_raw : 0.f);
+            reinterpret_cast<float*>(base + BIAS_OFF)[cq * TK + key] = bv;
+        }
+        advance(bly, blx);
+    };
+    auto stage_piece = [&](int i, unsigned char* base) {        // i = 0 .. NPIECE-1, compile-time after unrolling
+        const int j = i / (2 * NS), pl = (i / 2) % NS, isv = i & 1;
+        unsigned char* dst = base + (8 * wave + 4 * j) * 256 + (isv * NS + pl) * PLANE;
+        lds_dma16((isv ? spv[j] : spk[j]) + pl * a.plane_stride, dst);
+    };
+
+    // per-lane LDS read offsets (loop invariant)
+    int koff[8];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) koff[ks] = r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
+    }
     const int li = lane & 15, lg = (lane >> 4) & 1;
-    const unsigned char* vb = ldsV + (8 * half + (li >> 2)) * VROW + (16 * lg + 4 * (li & 3)) * 2;
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int t0 = t * 64;
-        __syncthreads();                       // everyone is done reading the previous tile
-        // ---- stage K and V tiles: 64 window tokens x 256 B per plane, gathered by token index ---------
-        {
-            long off[4];
+    int voff[4];
+    {
+        const int r3 = (li >> 2) & 3;                       // (row & 3) of every row this lane addresses
+        const int rowb = 8 * half + (li >> 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = (tid >> 4) + 16 * i;
-                int lab;
-                const int tk = t0 + key;
-                const int tok = window_token(a, wy, wx, min(tk, a.n - 1), lab);
-                off[i] = (sbase + tok) * UM_CHANNELS + (tid & 15) * 8;
-                if ((tid & 15) == 0) klab[key] = tk < a.n ? (unsigned char)lab : (unsigned char)255;
+        for (int dt = 0; dt < 4; ++dt)
+            voff[dt] = rowb * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
+    }
+
+    stage_prepare(0, lds);
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) stage_piece(i, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // One tile.  SLOT is a compile-time constant so that every LDS offset of the tile is an instruction immediate.
+    auto tile = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        UM_STAMP(0);
+        const bool staging = t + 1 < ntiles && !((UM_ABL & 8) && t > 0);
+        unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
+        if (staging) stage_prepare(t + 1, nxt);
+        const unsigned char* kb = lds + SLOT * BUF;
+        const unsigned char* vb = kb + NS * PLANE;
+
+        UM_STAMP(1);
+        // ---- S^T = K . Q^T for the 32 keys of the tile ---------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        {   // fragment reads run two k-steps ahead of the MFMAs that consume them
+            i16x8 fh[3], fl[3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fh[ks] = *reinterpret_cast<const i16x8*>(kb + koff[ks]);
+                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks]);
             }
-            i16x8 st[NS][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl) st[pl][i] = ld_global_16B(a.kp + pl * a.plane_stride + off[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl)
-                    *reinterpret_cast<i16x8*>(lds + pl * KPLANE + ((tid >> 4) + 16 * i) * KROW + (tid & 15) * 16) = st[pl][i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl) st[pl][i] = ld_global_16B(a.vp + pl * a.plane_stride + off[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl)
-                    *reinterpret_cast<i16x8*>(ldsV + pl * VPLANE + ((tid >> 4) + 16 * i) * VROW + (tid & 15) * 16) = st[pl][i];
-        }
-        __syncthreads();
-
-        // ---- S^T = K . Q^T for the two 32-key sub-tiles ------------------------------------------------
-        f32x16 sc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[0][r] = sc[1][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const i16x8 a0h = *reinterpret_cast<const i16x8*>(kb + ks * 32);
-            const i16x8 a1h = *reinterpret_cast<const i16x8*>(kb + 32 * KROW + ks * 32);
-            if (NS == 2) {
-                const i16x8 a0l = *reinterpret_cast<const i16x8*>(kb + KPLANE + ks * 32);
-                const i16x8 a1l = *reinterpret_cast<const i16x8*>(kb + KPLANE + 32 * KROW + ks * 32);
-                sc[0] = T::mfma(a0l, qf[0][ks], sc[0]);
-                sc[1] = T::mfma(a1l, qf[0][ks], sc[1]);
-                sc[0] = T::mfma(a0h, qf[NS - 1][ks], sc[0]);
-                sc[1] = T::mfma(a1h, qf[NS - 1][ks], sc[1]);
-            }
-            sc[0] = T::mfma(a0h, qf[0][ks], sc[0]);
-            sc[1] = T::mfma(a1h, qf[0][ks], sc[1]);
-        }
-
-        // ---- mask: region labels (shifted windows) and the ragged tail of the window ---------------------
-        if (has_mask || t0 + 64 > a.n) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned labs = *reinterpret_cast<const unsigned*>(klab + 32 * sub + 8 * g + 4 * half);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int lab = (labs >> (8 * i)) & 255;
-                        float v = sc[sub][4 * g + i];
-                        v = (has_mask && lab != labq) ? v + a.mask_raw : v;
-                        sc[sub][4 * g + i] = lab == 255 ? UM_NEG_MASK : v;
-                    }
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + koff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks + 2]);
                 }
+                if (staging && (ks * NPIECE) % 8 == 0) stage_piece(ks * NPIECE / 8, nxt);
+                if (UM_ABL & 4) {
+                    asm volatile("" : "+v"(fh[ks % 3]));
+                    if (NS == 2) asm volatile("" : "+v"(fl[ks % 3]));
+                    continue;
+                }
+                if (NS == 2) {
+                    sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
+                    sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
+                }
+                sc = T::mfma(fh[ks % 3], qf[0][ks], sc);
+            }
+            // Scheduling contract for hipcc (it otherwise emits read -> full wait -> MFMAs per k-step):
+            // fragment reads stay two k-steps ahead of the MFMAs that consume them.
+            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+        }
+
+        UM_STAMP(2);
+        // ---- additive bias: shifted-window mask (-100, unimatch/utils.py:106) and the ragged window tail -----
+        if (has_mask || (t + 1) * TK > a.n) {
+            const float* bt = reinterpret_cast<const float*>(kb + BIAS_OFF) + clsq * TK + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * g + i] += bv[i];
+            }
         }
 
         // ---- online softmax (row max shared by the lane pair l, l^32) ------------------------------------
-        float mx = sc[0][0];
+        float mx = sc[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+#ifdef UM_OLDMAX
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+#else
+        {   // max with the partner lane (l ^ 32) without touching LDS
+            float u, v2;
+            half_wave_pair(mx, u, v2);
+            mx = fmaxf(u, v2);
+        }
+#endif
         m = fmaxf(m, mx);
         const float Mn = -ceilf(m * c);
         if (Mn != M) {                          // exact power-of-two rescale (see global_match.hip)
@@ -194,25 +331,28 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
         }
         const float mc = M + (float)PSHIFT;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(__builtin_fmaf(sc[sub][r], c, mc));
-                sc[sub][r] = p;
-                l += p;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float p = (UM_ABL & 1) ? sc[r] : fast_exp2(__builtin_fmaf(sc[r], c, mc));
+            sc[r] = p;
+            l += p;
+        }
 
         // ---- P^T operand fragments: cvt + v_permlane32_swap, no LDS ---------------------------------------
-        // k-step ks (16 keys) uses regs 8*(ks&1)..+7 of sub-tile ks>>1; after the swaps a lane holds
-        // keys 8*half .. 8*half+7 of the step for its own query (B operand layout).
-        i16x8 pf[NS][4];
+        // k-step ks (16 keys) uses regs 8*ks..8*ks+7; after the swaps a lane holds keys 8*half .. 8*half+7 of
+        // the step for its own query (B operand layout).
+        i16x8 pf[NS][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int sub = ks >> 1, r0 = 8 * (ks & 1);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = 8 * ks;
             unsigned wh[4], wl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float p0 = sc[sub][r0 + 2 * j], p1 = sc[sub][r0 + 2 * j + 1];
+                const float p0 = sc[r0 + 2 * j], p1 = sc[r0 + 2 * j + 1];
+                if (UM_ABL & 1) {
+                    wh[j] = __builtin_bit_cast(unsigned, p0);
+                    wl[j] = __builtin_bit_cast(unsigned, p1);
+                    continue;
+                }
                 wh[j] = T::pack2(p0, p1);
                 if (NS == 2) {
                     const f32x2 hh = T::unpack2(wh[j]);
@@ -234,35 +374,77 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
         }
 
         // ---- O^T += V^T . P^T ----------------------------------------------------------------------------------
+        UM_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const unsigned char* va = vb + ks * 16 * VROW + dt * 64;
+                const unsigned char* va = vb + voff[dt] + ks * 16 * 256;
                 i16x8 vh, vl;
                 {
                     const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) i16x4*)(va));
                     const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) i16x4*)(va + 4 * VROW));
+                        (__attribute__((address_space(3))) i16x4*)(va + 4 * 256));
                     vh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 if (NS == 2) {
                     const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) i16x4*)(va + VPLANE));
+                        (__attribute__((address_space(3))) i16x4*)(va + PLANE));
                     const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) i16x4*)(va + VPLANE + 4 * VROW));
+                        (__attribute__((address_space(3))) i16x4*)(va + PLANE + 4 * 256));
                     vl = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
-                    o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
+                    if (UM_ABL & 2) {
+                        asm volatile("" : "+v"(vl), "+v"(pf[NS - 1][ks]));
+                    } else {
+                        o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
+                        o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
+                    }
                 }
-                o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
+                if (UM_ABL & 2) {
+                    asm volatile("" : "+v"(vh), "+v"(pf[0][ks]));
+                } else {
+                    o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
+                }
             }
         }
+        {   // transpose reads two (k-step, d-tile) groups ahead of the MFMAs
+            constexpr int RD = 2 * NS, MF = (NS == 2) ? 3 : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 1);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 1);
+        }
+        UM_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed in LDS
+        UM_STAMP(5);
+        if (!(UM_ABL & 16))
+            __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
+        UM_STAMP(6);
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
+#ifdef UM_TRACE
+    if (tracing) trace_buf[24 * 8 + 1] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- normalise and scatter back to the original token positions -----------------------------------------
-    const float lt = l + __shfl_xor(l, 32);
+    float lt;
+#ifdef UM_OLDSUM
+    lt = l + __shfl_xor(l, 32);
+#else
+    {
+        float u, v2;
+        half_wave_pair(l, u, v2);
+        lt = u + v2;
+    }
+#endif
     const float inv = 1.0f / lt;
     if (tq < a.n) {
         float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
@@ -280,6 +462,13 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WattnArgs a) {
 extern void um_set_error(const char* fmt, ...);
 
 static size_t align256w(size_t x) { return (x + 255) & ~(size_t)255; }
+
+#ifdef UM_TRACE
+extern "C" int um_debug_set_trace(void* ptr) {
+    unsigned long long* p = (unsigned long long*)ptr;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_um_trace), &p, sizeof(p));
+}
+#endif
 
 extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
     if (streams <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
