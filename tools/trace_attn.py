@@ -20,7 +20,7 @@ ops.window_attention(q, k, v, h, w, 32, 48, 0, 0)
 torch.cuda.synchronize()
 raw.um_debug_set_trace(ctypes.c_void_p(0))
 b = buf.cpu().view(-1, 24 * 8 + 8)
-names = ['stage-issue', 'QK', 'bias+softmax', 'PV', 'dma-wait', 'barrier']
+names = ['bias+rescale', 'QK+dma+addr', 'bias-add', 'PV||softmax', 'dma-wait', 'barrier']
 t0 = b[:, 24 * 8].min().item()
 for i in range(b.shape[0]):
     st = b[i, :24 * 8].view(24, 8)

@@ -319,10 +319,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
 #endif
         m = fmaxf(m, mx);
+        // Lazy, exact rescale.  The exponent offset M is an integer (every rescale factor is a power of two) and
+        // is allowed to lag the true running max by up to LAG: then p <= 2^(LAG + PSHIFT) = 2^15 still fits fp16,
+        // and the 64-accumulator rescale -- which otherwise fires on almost every tile because SOME of the wave's
+        // 32 rows moves -- becomes rare.  The branch is wave uniform; rows that did not move multiply by 1.
+        constexpr float LAG = (NS == 2) ? 1.f : 8.f;
         const float Mn = -ceilf(m * c);
-        if (Mn != M) {                          // exact power-of-two rescale (see global_match.hip)
-            const float resc = fast_exp2(Mn - M);
-            M = Mn;
+        const bool move = Mn + LAG < M;
+        if (__any(move)) {
+            const float resc = move ? fast_exp2(Mn - M) : 1.f;
+            M = move ? Mn : M;
             l *= resc;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
