@@ -127,13 +127,24 @@ def main():
     attn_flops = 4.0 * (2 * b) * L * n * c                          # QK^T + PV per launch
     gsv_flops = b * (2.0 * L * L * c + 4.0 * L * L)                 # per launch (corr or propagation)
     issued = 3.0 if args.precision == 'exact' else 1.0
+    # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be
+    # read from inside this process); the corrected per-launch figure for this exact launch shape is kept in
+    # profiles/ (see the note inside the file) and quoted here when the shape matches.
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_window_attn_gsv.json')))
+        if b == BATCH and args.precision == 'exact':
+            traffic = round(pm['window_attn_kernel<Fp16,2>']['hbm_traffic_bytes_per_launch'] / 1e6, 1)
+    except (OSError, KeyError, ValueError):
+        pass
     roof = None
     if attn_n:
         dur = attn_ms / attn_n * 1e-3
         ach = attn_flops / dur
         roof = {'kernel': 'window_attn_kernel', 'bound': 'mfma', 'achieved': round(ach / 1e12, 2),
                 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4),
-                'traffic': None, 'launches': attn_n, 'avg_launch_ms': round(attn_ms / attn_n, 4),
+                'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_window_attn_gsv.json)',
+                'launches': attn_n, 'avg_launch_ms': round(attn_ms / attn_n, 4),
                 'algorithmic_gflop_per_launch': round(attn_flops / 1e9, 2),
                 'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4)}
     roof2 = None
