@@ -57,7 +57,8 @@ const char* um_last_error_string(void);
 #define UM_K_COST_VOLUME 4   /* local_corr_with_flow_kernel                                              */
 #define UM_K_PROP_LOCAL 5    /* prop_local_attn_kernel                                                   */
 #define UM_K_DEPTH_CORR 6    /* depth_corr_softmax_kernel                                                */
-#define UM_K_COUNT 7
+#define UM_K_LINEAR 7        /* linear_kernel (um_linear_fwd)                                            */
+#define UM_K_COUNT 8
 int um_timing_enable(int on);
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
@@ -77,6 +78,39 @@ int um_window_attn_fwd(const float* q, const float* k, const float* v, float* ou
                        int streams, int h, int w, int channels,
                        int win_h, int win_w, int shift_h, int shift_w,
                        int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same attention core on operands that are ALREADY in the MFMA plane format ([NS][rows][ld] 16-bit, NS = 2 fp16
+ * planes hi|lo in UM_MODE_EXACT, 1 bf16 plane in UM_MODE_FAST; plane stride = rows * ld elements), e.g. the output
+ * of um_linear_fwd(epilogue = UM_EPI_PLANES).  q/k/v may be column slices of wider projections: ldq / ldkv are
+ * the row strides in elements (multiples of 8), rows = streams * h * w.  k and v share ldkv.  No workspace. */
+int um_window_attn_planes_fwd(const void* q_planes, const void* k_planes, const void* v_planes, float* out,
+                              int streams, int h, int w, int channels, int ldq, int ldkv,
+                              long q_plane_stride, long kv_plane_stride,
+                              int win_h, int win_w, int shift_h, int shift_w, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Transformer-layer linears  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear without bias) on MFMA with fused
+ * prologue / epilogue.  Replaces, per layer of unimatch/transformer.py: q/k/v projections (:58-60), merge +
+ * LayerNorm (+ residual) (:137-138,:144), and the FFN  cat[source, message] -> 8C -> GELU -> C -> LayerNorm ->
+ * + source (:141-144).  Same operand arithmetic as the attention kernels (`mode`).
+ *   weights : um_weight_planes() turns W [N,K] fp32 into planes pre-scaled by 2^wshift (exact; keeps the fp16
+ *             lo plane out of the subnormal range); pass the same wshift to um_linear_fwd.
+ *   input   : exactly one of  a0 (fp32 [M,K])  |  a0 + a1 (fp32 [M,K/2] each: K-concatenation without the
+ *             concatenated tensor)  |  a_planes ([NS][M][K]).
+ *   epilogue: UM_EPI_PLANES       out = planes [NS][M][N]
+ *             UM_EPI_LN           out = fp32 [M,N], N == 128: LayerNorm(gamma, beta, eps) (+ residual [M,N] if not NULL)
+ *             UM_EPI_GELU_PLANES  out = planes of erf-GELU(C)
+ * N must be a multiple of 128, K of 32 (64 with a1).
+ * ------------------------------------------------------------------------------------------- */
+#define UM_EPI_PLANES 0
+#define UM_EPI_LN 1
+#define UM_EPI_GELU_PLANES 2
+size_t um_planes_bytes(long rows, int cols, int mode);
+int um_weight_planes(const float* w, void* planes, int n, int k, int wshift, int mode, void* stream);
+int um_linear_fwd(const float* a0, const float* a1, const void* a_planes, const void* w_planes,
+                  int m, int n, int k, int wshift, int epilogue, void* out,
+                  const float* gamma, const float* beta, const float* residual, float eps,
+                  int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs correlation + softmax + expected coordinate (flow).

@@ -294,3 +294,75 @@ def test_fast_mode_runs_and_is_in_the_ballpark():
     pred, truth, _ = run_product('gmflow_s1', precision='fast')
     assert torch.isfinite(pred).all()
     assert (pred.double() - truth).abs().mean().item() < 2.0     # bf16 operands: px-level, reported not gated
+
+
+# ------------------------------------------------------------------ fused Transformer-layer tail (um_linear_fwd)
+def _planes_to_float(planes, m, n, nplanes):
+    halves = planes.view(torch.float16 if nplanes == 2 else torch.bfloat16).view(nplanes, m, n).float()
+    return halves.sum(0)
+
+
+@pytest.mark.parametrize('mk', [(300, 128, 128), (257, 384, 128), (128, 1024, 256)])
+def test_linear_planes_and_gelu(ops, mk):
+    """A . W^T written as operand planes (ragged M, fused q|k|v width, FFN width with the K-concatenated input
+    and the erf-GELU epilogue) against fp64.  Tolerance: the planes carry 22 bits, the product is fp32-accurate."""
+    m, n, k = mk
+    a = rnd(70, m, k, scale=2.0)
+    w = rnd(71, n, k, scale=0.1)
+    want = a.double() @ w.double().t()
+    if k == 256:
+        a0, a1 = a[:, :128].contiguous(), a[:, 128:].contiguous()
+        got, _, _ = ops.linear_planes(a0.to(DEV), (w.to(DEV),), a1=a1.to(DEV), gelu=True)
+        want = torch.nn.functional.gelu(want)
+    else:
+        chunks = tuple(x.contiguous().to(DEV) for x in w.split(128, 0))
+        got, _, _ = ops.linear_planes(a.to(DEV), chunks)
+    got = _planes_to_float(got.cpu(), m, n, 2)
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_linear_layernorm_residual(ops):
+    m = 333
+    a = rnd(72, m, 128, scale=2.0)
+    w = rnd(73, 128, 128, scale=0.1)
+    res = rnd(74, m, 128)
+    norm = torch.nn.LayerNorm(128)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * rnd(75, 128))
+        norm.bias.copy_(0.1 * rnd(76, 128))
+    want = torch.nn.functional.layer_norm(a.double() @ w.double().t(), (128,), norm.weight.double(), norm.bias.double(),
+                                          norm.eps)
+    norm = norm.to(DEV)
+    got = ops.linear_ln(a.to(DEV), (w.to(DEV),), norm)
+    assert err(got, want)[0] < 2e-5
+    got = ops.linear_ln(a.to(DEV), (w.to(DEV),), norm, residual=res.to(DEV))
+    assert err(got, want + res.double())[0] < 2e-5
+    # planes input (the FFN's second GEMM): K = 1024
+    hid = rnd(77, m, 1024)
+    w2 = rnd(78, 128, 1024, scale=0.05)
+    ident = torch.eye(1024)
+    hp_, _, _ = ops.linear_planes(hid.to(DEV), tuple(x.contiguous().to(DEV) for x in ident.split(128, 0)))   # hid as planes
+    got = ops.linear_ln(hp_, (w2.to(DEV),), norm, residual=res.to(DEV), a_planes_k=1024)
+    want = torch.nn.functional.layer_norm(hid.double() @ w2.double().t(), (128,), norm.weight.double().cpu(),
+                                          norm.bias.double().cpu(), norm.eps) + res.double()
+    assert err(got, want)[0] < 5e-5
+
+
+def test_fused_layer_matches_unfused_layer(ops, golden):
+    """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
+    g = golden('transformer')
+    proto = UniMatch().transformer
+    sd = synth_state_dict({k: v.shape for k, v in proto.state_dict().items()}, seed=7)
+    proto.load_state_dict(sd)
+    proto = proto.to(DEV)
+    from unimatch_amd.model import _to_tokens, _to_map
+    for attn_type, k in (('swin', 2), ('self_swin2d_cross_swin1d', 4)):
+        tag = f'{attn_type}_k{k}'
+        f0, f1 = g[f'{tag}.f0'], g[f'{tag}.f1']
+        h, w = f0.shape[-2:]
+        o0, o1 = proto(ops, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
+        want0, want1 = hp.feature_transformer(f0.double(), f1.double(), {kk: v.double() for kk, v in sd.items()},
+                                              attn_type, k)
+        assert err(_to_map(o0, h, w), want0)[0] < 2e-4, tag
+        assert err(_to_map(o1, h, w), want1)[0] < 2e-4, tag
+        assert err(_to_map(o0, h, w), g[f'{tag}.o0'])[0] < 4e-4, tag

@@ -35,14 +35,23 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
-// rows*128 fp32 values -> planes at dst.  Returns hipError_t of the launch.
+// n_elems fp32 values (a multiple of 8) -> planes at dst, plane stride n_elems.  Returns hipError_t of the launch.
+static inline hipError_t launch_split_elems(const float* src, unsigned short* dst, long n_elems, float scale,
+                                            int mode, hipStream_t stream);
+
+// rows*128 fp32 values -> planes at dst.
 static inline hipError_t launch_split_planes(const float* src, unsigned short* dst, long rows, float scale,
                                              int mode, hipStream_t stream) {
-    const long n8 = rows * (UM_CHANNELS / 8);
+    return launch_split_elems(src, dst, rows * UM_CHANNELS, scale, mode, stream);
+}
+
+static inline hipError_t launch_split_elems(const float* src, unsigned short* dst, long n_elems, float scale,
+                                            int mode, hipStream_t stream) {
+    const long n8 = n_elems / 8;
     long blocks = (n8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    const long plane_stride = rows * UM_CHANNELS;
+    const long plane_stride = n_elems;
     ScopedKernelTimer timer(UM_K_SPLIT_PLANES, stream);
     if (mode == 0)
         hipLaunchKernelGGL((split_planes_kernel<Fp16, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n8,

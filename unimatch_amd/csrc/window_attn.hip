@@ -44,7 +44,9 @@ struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
     const unsigned short* kp;
     const unsigned short* vp;
-    long plane_stride;           // S * L * 128
+    long plane_stride;           // q planes: rows * ldq
+    long kv_plane_stride;        // k, v planes: rows * ldkv
+    int ldq, ldkv;               // row strides in elements (128 for dedicated tensors; 256 / 384 for fused projections)
     float* out;                  // [S][L][128]
     int h, w, win_h, win_w, shift_h, shift_w;
     int nwx, nwin;               // windows per row, windows per stream
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
     i16x8 qf[NS][8];
     {
-        const unsigned short* qb = a.qp + (sbase + tokq) * UM_CHANNELS + 8 * half;
+        const unsigned short* qb = a.qp + (sbase + tokq) * a.ldq + 8 * half;
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             int cls;
             const int tok = token_at(sly[j], slx[j], cls);
             advance(sly[j], slx[j]);
-            const long goff = (sbase + tok) * UM_CHANNELS;
+            const long goff = (sbase + tok) * a.ldkv;
             spk[j] = a.kp + goff + ssrc_k[j];
             spv[j] = a.vp + goff + ssrc_v[j];
         }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto stage_piece = [&](int i, unsigned char* base) {        // i = 0 .. NPIECE-1, compile-time after unrolling
         const int j = i / (2 * NS), pl = (i / 2) % NS, isv = i & 1;
         unsigned char* dst = base + (8 * wave + 4 * j) * 256 + (isv * NS + pl) * PLANE;
-        lds_dma16((isv ? spv[j] : spk[j]) + pl * a.plane_stride, dst);
+        lds_dma16((isv ? spv[j] : spk[j]) + pl * a.kv_plane_stride, dst);
     };
 
     // per-lane LDS read offsets (loop invariant)
@@ -476,16 +478,13 @@ extern "C" int um_debug_set_trace(void* ptr) {
 }
 #endif
 
-extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
-    if (streams <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
-    return 3 * align256w(planes_bytes((long)streams * tokens, mode));
-}
+static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
+                              int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
+                              int win_h, int win_w, int shift_h, int shift_w, int mode, hipStream_t stream);
 
-extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v, float* out, int streams, int h,
-                                  int w, int channels, int win_h, int win_w, int shift_h, int shift_w, int mode,
-                                  void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!q || !k || !v || !out || streams <= 0 || h <= 0 || w <= 0) {
+static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
+                               int mode) {
+    if (streams <= 0 || h <= 0 || w <= 0) {
         um_set_error("null pointer or non-positive size (streams=%d h=%d w=%d)", streams, h, w);
         return -1;
     }
@@ -507,6 +506,41 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
         um_set_error("shift (%d,%d) invalid for window %dx%d on a %dx%d map", shift_h, shift_w, win_h, win_w, h, w);
         return -2;
     }
+    return 0;
+}
+
+extern "C" int um_window_attn_planes_fwd(const void* qp, const void* kp, const void* vp, float* out, int streams,
+                                         int h, int w, int channels, int ldq, int ldkv, long q_plane_stride,
+                                         long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w,
+                                         int mode, void* stream) {
+    if (!qp || !kp || !vp || !out) {
+        um_set_error("null pointer");
+        return -1;
+    }
+    if (int e = check_attn_geometry(streams, h, w, channels, win_h, win_w, shift_h, shift_w, mode)) return e;
+    if (ldq < UM_CHANNELS || ldkv < UM_CHANNELS || ldq % 8 || ldkv % 8) {
+        um_set_error("row strides ldq=%d ldkv=%d must be multiples of 8 and >= %d", ldq, ldkv, UM_CHANNELS);
+        return -1;
+    }
+    return launch_window_attn((const unsigned short*)qp, (const unsigned short*)kp, (const unsigned short*)vp, out,
+                              streams, h, w, ldq, ldkv, q_plane_stride, kv_plane_stride, win_h, win_w, shift_h, shift_w,
+                              mode, (hipStream_t)stream);
+}
+
+extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
+    if (streams <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
+    return 3 * align256w(planes_bytes((long)streams * tokens, mode));
+}
+
+extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v, float* out, int streams, int h,
+                                  int w, int channels, int win_h, int win_w, int shift_h, int shift_w, int mode,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !k || !v || !out) {
+        um_set_error("null pointer");
+        return -1;
+    }
+    if (int e = check_attn_geometry(streams, h, w, channels, win_h, win_w, shift_h, shift_w, mode)) return e;
     const long L = (long)h * w;
     const size_t need = um_window_attn_workspace_bytes(streams, (int)L, channels, mode);
     if (!workspace || workspace_bytes < need) {
@@ -523,11 +557,21 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
     if ((e = launch_split_planes(k, pk, streams * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
     if ((e = launch_split_planes(v, pv, streams * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
 
+    return launch_window_attn(pq, pk, pv, out, streams, h, w, UM_CHANNELS, UM_CHANNELS, streams * L * UM_CHANNELS,
+                              streams * L * UM_CHANNELS, win_h, win_w, shift_h, shift_w, mode, stream);
+}
+
+static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
+                              int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
+                              int win_h, int win_w, int shift_h, int shift_w, int mode, hipStream_t stream) {
     WattnArgs a;
     a.qp = pq;
     a.kp = pk;
     a.vp = pv;
-    a.plane_stride = streams * L * UM_CHANNELS;
+    a.plane_stride = q_plane_stride;
+    a.kv_plane_stride = kv_plane_stride;
+    a.ldq = ldq;
+    a.ldkv = ldkv;
     a.out = out;
     a.h = h;
     a.w = w;
@@ -540,8 +584,8 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
     a.n = win_h * win_w;
     a.nqt = (a.n + 127) / 128;
     a.total = a.nqt * a.nwin * streams;
-    a.scale_log2 = UM_LOG2E / sqrtf((float)channels);
-    a.mask_raw = -100.0f * sqrtf((float)channels);
+    a.scale_log2 = UM_LOG2E / sqrtf((float)UM_CHANNELS);
+    a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (mode == 0)
         hipLaunchKernelGGL((window_attn_kernel<Fp16, 2>), dim3(a.total), dim3(256), 0, stream, a);

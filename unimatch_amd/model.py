@@ -106,12 +106,34 @@ class TransformerLayer(nn.Module):
             self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, ops, source, target, h, w, geom):
+        if getattr(ops, 'fused_tail', False):
+            return self._forward_fused(ops, source, target, h, w, geom)
         q, k, v = self.q_proj(source), self.k_proj(target), self.v_proj(target)
         msg = ops.window_attention(q, k, v, h, w, *geom)
         msg = self.norm1(self.merge(msg))
         if not self.no_ffn:
             msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
         return source + msg
+
+    def _forward_fused(self, ops, source, target, h, w, geom):
+        """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
+        (+ residual) is one kernel, the FFN is two kernels with no concatenated / fp32 hidden tensor."""
+        s, l, c = source.shape
+        m = s * l
+        src = source.reshape(m, c)
+        if target is source:                       # self attention: one projection launch for q | k | v
+            qkv, _, n3 = ops.linear_planes(src, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight))
+            q, k, v = (qkv, m, n3, 0), (qkv, m, n3, c), (qkv, m, n3, 2 * c)
+        else:
+            qp, _, _ = ops.linear_planes(src, (self.q_proj.weight,))
+            kv, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
+            q, k, v = (qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c)
+        att = ops.window_attention_planes(q, k, v, s, h, w, *geom).reshape(m, c)
+        if self.no_ffn:
+            return ops.linear_ln(att, (self.merge.weight,), self.norm1, residual=src).reshape(s, l, c)
+        msg = ops.linear_ln(att, (self.merge.weight,), self.norm1)
+        hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)
+        return ops.linear_ln(hid, (self.mlp[2].weight,), self.norm2, residual=src, a_planes_k=nh).reshape(s, l, c)
 
 
 class TransformerBlock(nn.Module):

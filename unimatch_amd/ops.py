@@ -54,6 +54,9 @@ def _check_map(name, t, n, h, w):
 class HipOps:
     """The hot path on MI355X.  ``precision``: 'exact' (fp16 hi+lo split MFMA operands) or 'fast' (bf16)."""
 
+    fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
+    WSHIFT = 10                # weights are scaled by 2^10 before the fp16 split (exact), see linear.hip
+
     def __init__(self, precision='exact'):
         if precision not in PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(PRECISIONS)}')
@@ -63,6 +66,8 @@ class HipOps:
         self.precision = precision
         self.mode = PRECISIONS[precision]
         self.timer = None                     # set to a KernelTimer() to time launches with HIP events
+        self.nplanes = 2 if precision == 'exact' else 1
+        self._wcache = {}                     # weight planes, keyed by the identity + version of the fp32 tensors
 
     # ------------------------------------------------------------------ helpers
     def _ws(self, nbytes, device):
@@ -94,6 +99,85 @@ class HipOps:
             _ptr(q), _ptr(k), _ptr(v), _ptr(out), s, h, w, c, win_h, win_w, shift_h, shift_w,
             self.mode, _ptr(ws), ws.numel(), _stream()), meta)
         _abi.check(code, 'um_window_attn_fwd')
+        return out
+
+    # ------------------------------------------------------------------ fused Transformer-layer tail
+    def weight_planes(self, weights):
+        """MFMA operand planes of ``cat(weights, 0)`` ([N, K] fp32 each, same K), cached until a weight changes."""
+        key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
+        hit = self._wcache.get(key)
+        if hit is not None:
+            return hit
+        w = (weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)).detach().float().contiguous()
+        n, k = w.shape
+        planes = torch.empty(self.lib.um_planes_bytes(n, k, self.mode), dtype=torch.uint8, device=w.device)
+        _abi.check(self.lib.um_weight_planes(_ptr(w), _ptr(planes), n, k, self.WSHIFT, self.mode, _stream()),
+                   'um_weight_planes')
+        if len(self._wcache) > 256:
+            self._wcache.clear()
+        self._wcache[key] = (planes, n, k)
+        return self._wcache[key]
+
+    def _check_rows(self, name, t, k):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.shape[1] == k):
+            raise ValueError(f'{name}: expected a contiguous CUDA float32 [M, {k}] tensor, got {tuple(t.shape)} {t.dtype}')
+
+    def linear_planes(self, a, weights, a1=None, gelu=False, a_planes_k=None):
+        """``(gelu)(A . cat(weights)^T)`` written as MFMA operand planes ``[NS][M][N]`` (flat uint8 tensor).
+
+        A is ``a`` fp32 ``[M, K]``, or the K-concatenation of ``a`` and ``a1`` (``[M, K/2]`` each), or -- with
+        ``a_planes_k`` -- ``a`` is already a plane tensor with K = a_planes_k columns."""
+        wp, n, k = self.weight_planes(weights)
+        if a_planes_k is not None:
+            m = a.numel() // (2 * self.nplanes * a_planes_k)
+            args = (None, None, _ptr(a))
+        else:
+            m = a.shape[0]
+            self._check_rows('a', a, k // 2 if a1 is not None else k)
+            if a1 is not None:
+                self._check_rows('a1', a1, k // 2)
+            args = (_ptr(a), _ptr(a1) if a1 is not None else None, None)
+        out = torch.empty(self.lib.um_planes_bytes(m, n, self.mode), dtype=torch.uint8, device=a.device)
+        meta = {'flops': 2.0 * m * n * k}
+        code = self._launch('linear', lambda: self.lib.um_linear_fwd(
+            args[0], args[1], args[2], _ptr(wp), m, n, k, self.WSHIFT, 2 if gelu else 0, _ptr(out),
+            None, None, None, 0.0, self.mode, _stream()), meta)
+        _abi.check(code, 'um_linear_fwd')
+        return out, m, n
+
+    def linear_ln(self, a, weights, norm, residual=None, a_planes_k=None):
+        """``LayerNorm(A . W^T) (+ residual)`` -> fp32 ``[M, 128]``; ``norm`` is an ``nn.LayerNorm`` over 128."""
+        wp, n, k = self.weight_planes(weights)
+        if a_planes_k is not None:
+            m = a.numel() // (2 * self.nplanes * a_planes_k)
+            args = (None, None, _ptr(a))
+        else:
+            m = a.shape[0]
+            self._check_rows('a', a, k)
+            args = (_ptr(a), None, None)
+        if residual is not None:
+            self._check_rows('residual', residual, n)
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        code = self._launch('linear', lambda: self.lib.um_linear_fwd(
+            args[0], args[1], args[2], _ptr(wp), m, n, k, self.WSHIFT, 1, _ptr(out),
+            _ptr(norm.weight), _ptr(norm.bias), _ptr(residual) if residual is not None else None,
+            float(norm.eps), self.mode, _stream()), {'flops': 2.0 * m * n * k})
+        _abi.check(code, 'um_linear_fwd')
+        return out
+
+    def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0):
+        """Attention on operand planes.  q, k, v: ``(plane_tensor, rows, cols, col_offset)`` -- a 128-column slice
+        starting at ``col_offset`` of a ``[NS][rows][cols]`` plane tensor (k and v must share their tensor's shape)."""
+        (qt, qrows, qcols, qoff), (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = q, k, v
+        if (krows, kcols) != (vrows, vcols) or qrows != streams * h * w or krows != qrows:
+            raise ValueError('inconsistent plane shapes')
+        out = torch.empty((streams, h * w, 128), dtype=torch.float32, device=qt.device)
+        n = win_h * win_w
+        meta = {'flops': 4.0 * streams * h * w * n * 128}
+        code = self._launch('window_attn', lambda: self.lib.um_window_attn_planes_fwd(
+            _ptr(qt) + 2 * qoff, _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(out), streams, h, w, 128,
+            qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, self.mode, _stream()), meta)
+        _abi.check(code, 'um_window_attn_planes_fwd')
         return out
 
     # ------------------------------------------------------------------ global matching
