@@ -61,7 +61,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     import torch.distributed as dist
-    distributed = world > 1
+    # UM_BENCH_FORCE_DIST=1 exercises the RCCL path (process group + all-gather) even with a single rank
+    distributed = world > 1 or os.environ.get('UM_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
