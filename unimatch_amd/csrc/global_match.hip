@@ -17,6 +17,7 @@
 // them and keep INDEPENDENT running maxima, merged once at the end (no cross-lane traffic per tile).
 // K tiles are staged through LDS (rows padded to 272 B: conflict-free ds_read_b128 A-fragments) with
 // the next tile's global loads in flight during the current tile's MFMAs.
+#include <type_traits>
 #include "common.h"
 #include "planes.h"
 
@@ -30,16 +31,45 @@ struct GsvArgs {
     int Lq, Lk;
     float scale_log2;           // log2(e) / sqrt(C)
     float alpha, beta;
+    int nsplit;                 // key range split across gridDim.z workgroups (load balance); 1 = direct output
+    float* partial;             // nsplit > 1: [nsplit][nbatch][Lq][2 + NV] = (M, l, acc...) per split
 };
+
+// 16 (or 4) bytes per lane, global -> LDS without passing through VGPRs (LDS address = wave-uniform dst + size * lane).
+// Issued through inline asm: hipcc would otherwise drain the transfer in front of the next LDS read (see window_attn.hip).
+__device__ __forceinline__ void gsv_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void gsv_dma4(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(dst)
+                 : "memory");
+}
 
 template <class T, int NS, int NV, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
-    constexpr int KROW = 272;                 // 128 * 2 B + 16 B pad
-    constexpr int KPLANE = 64 * KROW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * KPLANE + NV * 64 * 4];
-    float* vt = reinterpret_cast<float*>(lds + NS * KPLANE);
+    // LDS ring, two slots of one 64-key tile each: K planes as linear 256-byte rows whose 16-byte chunks are
+    // XOR-swizzled by (row & 15) through the SOURCE address (LDS-DMA writes lane-linear; ds_read_b128 A fragments
+    // then are conflict free), followed by the tile's values [NV][64] fp32.  Tile t+1 streams in by LDS-DMA while
+    // tile t is consumed; one barrier per tile.
+    constexpr int TK = 64;
+    constexpr int PLANE = TK * 256;
+    constexpr int VOFF = NS * PLANE;
+    constexpr int SLOT = VOFF + NV * TK * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int b = blockIdx.y;
     const int qwg = blockIdx.x * 128;
@@ -55,44 +85,36 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
         for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.q_plane_stride + 16 * ks);
+        // retire these loads before the loop: inside it hipcc's vmcnt scoreboard must stay empty (hidden DMA)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
     }
 
-    int ntiles = (a.Lk + 63) >> 6;
-    if (CAUSAL) ntiles = min(ntiles, (min(qwg + 127, a.Lq - 1) >> 6) + 1);
+    int ntiles = (a.Lk + TK - 1) / TK;
+    if (CAUSAL) ntiles = min(ntiles, (min(qwg + 127, a.Lq - 1) / TK) + 1);
+    // split-KV: this workgroup owns key tiles [tbeg, tend)
+    const int per = (ntiles + a.nsplit - 1) / a.nsplit;
+    const int tbeg = blockIdx.z * per, tend = min(ntiles, tbeg + per);
 
-    // ---- staging: next K tile (and its values) travel HBM -> registers during the MFMAs --------
-    i16x8 st[NS][4];
-    float sv[NV];
-    const unsigned short* kbase = a.kp + (long)b * a.Lk * UM_CHANNELS;
-    const float* vbase = a.v + (long)b * a.v_batch_stride;
-
-    auto issue = [&](int t) {
-        const int t0 = t * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + 256 * i;
-            const int kr = min(t0 + (id >> 4), a.Lk - 1);
-            const unsigned short* src = kbase + (long)kr * UM_CHANNELS + (id & 15) * 8;
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl) st[pl][i] = ld_global_16B(src + pl * a.k_plane_stride);
-        }
-        if (tid < 64) {
-            const int kr = min(t0 + tid, a.Lk - 1);
-#pragma unroll
-            for (int ch = 0; ch < NV; ++ch) sv[ch] = vbase[ch * a.v_chan_stride + kr];
-        }
+    // ---- staging: wave w moves rows 16w .. 16w+15 of a tile, 4 rows (64 lanes x 16 B) per DMA instruction ----
+    const unsigned kbase_bytes = (unsigned)((long)b * a.Lk * UM_CHANNELS * 2);
+    const int srow = 16 * wave + (lane >> 4);                    // + 4 * j
+    const int scp = lane & 15;
+    constexpr int NPIECE = 4 * NS;                               // K pieces per wave per tile
+    auto k_piece = [&](int t, int i, unsigned char* slot) {     // i = 0 .. NPIECE-1
+        const int j = i / NS, pl = i % NS;
+        const int row = srow + 4 * j;
+        const int key = min(t * TK + row, a.Lk - 1);
+        const unsigned off = kbase_bytes + (unsigned)key * (UM_CHANNELS * 2) + ((scp ^ (row & 15)) << 4);
+        gsv_dma16(a.kp + pl * a.k_plane_stride, off, slot + pl * PLANE + (16 * wave + 4 * j) * 256);
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + 256 * i;
-            unsigned char* dst = lds + (id >> 4) * KROW + (id & 15) * 16;
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<i16x8*>(dst + pl * KPLANE) = st[pl][i];
-        }
-        if (tid < 64) {
-#pragma unroll
-            for (int ch = 0; ch < NV; ++ch) vt[ch * 64 + tid] = sv[ch];
+    const float* vbase = a.v + (long)b * a.v_batch_stride;
+    auto v_piece = [&](int t, unsigned char* slot) {             // wave ch stages channel ch (64 lanes x 4 B)
+        if (wave < NV) {
+            const int key = min(t * TK + lane, a.Lk - 1);
+            gsv_dma4(vbase + wave * a.v_chan_stride, (unsigned)key * 4, slot + VOFF + wave * TK * 4);
         }
     };
 
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
     for (int ch = 0; ch < NV; ++ch) acc[ch] = 0.f;
 
     // online-softmax update with the 16 scores this lane holds of a 32-key sub-tile
-    auto update = [&](f32x16 s, int key0 /* first key of the sub-tile */, int ldsk0 /* its slot in the tile */) {
+    auto update = [&](f32x16 s, int key0 /* first key of the sub-tile */, const float* vt, int ldsk0) {
         const int kl = key0 + 4 * half;
         if (CAUSAL || key0 + 32 > a.Lk) {
 #pragma unroll
@@ -115,9 +137,8 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
                 s[r] = ok ? s[r] : UM_NEG_MASK;
             }
         }
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
         m = fmaxf(m, mx);
         const float Mn = -ceilf(m * c);
         const float resc = fast_exp2(Mn - M);
@@ -126,48 +147,98 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
 #pragma unroll
         for (int ch = 0; ch < NV; ++ch) acc[ch] *= resc;
         const float mc = M;
+        float l0 = 0.f, l1 = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 vv[NV];
 #pragma unroll
             for (int ch = 0; ch < NV; ++ch)
-                vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * 64 + ldsk0 + 8 * g + 4 * half);
+                vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + ldsk0 + 8 * g + 4 * half);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float p = fast_exp2(__builtin_fmaf(s[4 * g + i], c, mc));
-                l += p;
+                if (i & 1) l1 += p; else l0 += p;
 #pragma unroll
                 for (int ch = 0; ch < NV; ++ch) acc[ch] = __builtin_fmaf(p, vv[ch][i], acc[ch]);
             }
         }
+        l += l0 + l1;
     };
 
-    issue(0);
-    for (int t = 0; t < ntiles; ++t) {
-        commit();
-        __syncthreads();
-        if (t + 1 < ntiles) issue(t + 1);
+    // per-lane fragment address: row * 256 + ((2 ks + half) ^ (row & 15)) * 16  ==  kaddr ^ (ks << 5)
+    int kaddr;
+    {
+        const int r = lane & 31, x = r & 15;
+        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
+    }
 
-        f32x16 s0 = {0}, s1 = {0};
-        const unsigned char* kb = lds + (lane & 31) * KROW + half * 16;
+    // ---- prologue: tile 0 into slot 0 ----------------------------------------------------------------------
+    if (tbeg < tend) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const i16x8 a0h = *reinterpret_cast<const i16x8*>(kb + ks * 32);
-            const i16x8 a1h = *reinterpret_cast<const i16x8*>(kb + 32 * KROW + ks * 32);
+        for (int i = 0; i < NPIECE; ++i) k_piece(tbeg, i, lds);
+        v_piece(tbeg, lds);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tile = [&](auto slot_c, int t) {
+        constexpr int SL = decltype(slot_c)::value;
+        const unsigned char* cur = lds + SL * SLOT;
+        unsigned char* nxt = lds + (SL ^ 1) * SLOT;
+        const bool staging = t + 1 < tend;
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+        {
+            i16x8 f0h[2], f0l[2], f1h[2], f1l[2];               // sub-tile 0 / 1 fragments, one k-step ahead
+            f0h[0] = *reinterpret_cast<const i16x8*>(cur + kaddr);
+            f1h[0] = *reinterpret_cast<const i16x8*>(cur + 32 * 256 + kaddr);
             if (NS == 2) {
-                const i16x8 a0l = *reinterpret_cast<const i16x8*>(kb + KPLANE + ks * 32);
-                const i16x8 a1l = *reinterpret_cast<const i16x8*>(kb + KPLANE + 32 * KROW + ks * 32);
-                s0 = T::mfma(a0l, qf[0][ks], s0);
-                s1 = T::mfma(a1l, qf[0][ks], s1);
-                s0 = T::mfma(a0h, qf[NS - 1][ks], s0);
-                s1 = T::mfma(a1h, qf[NS - 1][ks], s1);
+                f0l[0] = *reinterpret_cast<const i16x8*>(cur + PLANE + kaddr);
+                f1l[0] = *reinterpret_cast<const i16x8*>(cur + PLANE + 32 * 256 + kaddr);
             }
-            s0 = T::mfma(a0h, qf[0][ks], s0);
-            s1 = T::mfma(a1h, qf[0][ks], s1);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int bq = ks & 1, nb = bq ^ 1;
+                if (ks + 1 < 8) {
+                    const int ka = kaddr ^ ((ks + 1) << 5);
+                    f0h[nb] = *reinterpret_cast<const i16x8*>(cur + ka);
+                    f1h[nb] = *reinterpret_cast<const i16x8*>(cur + 32 * 256 + ka);
+                    if (NS == 2) {
+                        f0l[nb] = *reinterpret_cast<const i16x8*>(cur + PLANE + ka);
+                        f1l[nb] = *reinterpret_cast<const i16x8*>(cur + PLANE + 32 * 256 + ka);
+                    }
+                }
+                if (staging && (ks * NPIECE) % 8 == 0) k_piece(t + 1, ks * NPIECE / 8, nxt);
+                if (staging && ks == 7) v_piece(t + 1, nxt);
+                if (NS == 2) {
+                    s0 = T::mfma(f0l[bq], qf[0][ks], s0);
+                    s1 = T::mfma(f1l[bq], qf[0][ks], s1);
+                    s0 = T::mfma(f0h[bq], qf[NS - 1][ks], s0);
+                    s1 = T::mfma(f1h[bq], qf[NS - 1][ks], s1);
+                }
+                s0 = T::mfma(f0h[bq], qf[0][ks], s0);
+                s1 = T::mfma(f1h[bq], qf[0][ks], s1);
+            }
+            // fragment reads stay one k-step ahead of the MFMAs that consume them
+            constexpr int RD = 2 * NS, MF = 2 * ((NS == 2) ? 3 : 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
         }
-        update(s0, t * 64, 0);
-        update(s1, t * 64 + 32, 32);
-        __syncthreads();
+        const float* vt = reinterpret_cast<const float*>(cur + VOFF);
+        update(s0, t * TK, vt, 0);
+        update(s1, t * TK + 32, vt, 32);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t+1 has landed
+        __syncthreads();                                        // ... everyone's has; tile t is fully consumed
+    };
+    for (int t = tbeg; t < tend; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < tend) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
     // ---- merge the two half-waves' partial softmaxes and write ------------------------------------
@@ -176,6 +247,19 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
     const float MM = fminf(M, M2);
     const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
     const float lt = l * f1 + l2 * f2;
+    if (a.nsplit > 1) {          // partial result of this key range; gsv_combine_kernel finishes the softmax
+        float* pr = a.partial + (((long)blockIdx.z * gridDim.y + b) * a.Lq + qi) * (2 + NV);
+        if (half == 0 && qi < a.Lq) {
+            pr[0] = MM;
+            pr[1] = lt;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) {
+            const float a2 = __shfl_xor(acc[ch], 32);
+            if (half == 0 && qi < a.Lq) pr[2 + ch] = acc[ch] * f1 + a2 * f2;
+        }
+        return;
+    }
 #pragma unroll
     for (int ch = 0; ch < NV; ++ch) {
         const float a2 = __shfl_xor(acc[ch], 32);
@@ -185,6 +269,34 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
             if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi];
             a.out[((long)b * NV + ch) * a.Lq + qi] = r;
         }
+    }
+}
+
+// merge the per-split partial softmaxes: out = alpha * sum_s(acc_s 2^(M-M_s)) / sum_s(l_s 2^(M-M_s)) + beta * v[query]
+template <int NV>
+__global__ void gsv_combine_kernel(GsvArgs a, int nbatch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)nbatch * a.Lq;
+    if (i >= total) return;
+    const int b = (int)(i / a.Lq), q = (int)(i - (long)b * a.Lq);
+    float MM = 3.0e38f;
+    for (int sp = 0; sp < a.nsplit; ++sp) MM = fminf(MM, a.partial[((long)sp * total + i) * (2 + NV)]);
+    float lt = 0.f, at[NV];
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) at[ch] = 0.f;
+    for (int sp = 0; sp < a.nsplit; ++sp) {
+        const float* pr = a.partial + ((long)sp * total + i) * (2 + NV);
+        const float f = fast_exp2(MM - pr[0]);
+        lt += pr[1] * f;
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) at[ch] += pr[2 + ch] * f;
+    }
+    const float* vbase = a.v + (long)b * a.v_batch_stride;
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) {
+        float r = a.alpha * (at[ch] / lt);
+        if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + q];
+        a.out[((long)b * NV + ch) * a.Lq + q] = r;
     }
 }
 
@@ -201,22 +313,47 @@ __global__ void fill_grid_kernel(float* g, int h, int w) {
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
 
+#define GSV_MAX_SPLIT 8
+// Key-range split so that the launch is a whole number of balanced rounds: 256 CUs x 2 resident workgroups.
+static int gsv_choose_split(int qtiles, int nbatch, int ktiles) {
+    const long wgs = (long)qtiles * nbatch;
+    int best = 1;
+    if (wgs >= 1536 || ktiles < 16) return 1;
+    for (int sp = 1; sp <= GSV_MAX_SPLIT && ktiles / sp >= 8; ++sp) {
+        best = sp;
+        if (wgs * sp >= 1536) break;
+    }
+    return best;
+}
+
 template <int NV, bool CAUSAL>
-static hipError_t launch_gsv(const GsvArgs& a, int nbatch, int mode, hipStream_t stream) {
-    dim3 grid((a.Lq + 127) / 128, nbatch), block(256);
-    ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
-    if (mode == 0)
-        hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((gsv_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
-    return hipGetLastError();
+static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
+    const int qtiles = (a.Lq + 127) / 128;
+    a.nsplit = (CAUSAL || !partial) ? 1 : gsv_choose_split(qtiles, nbatch, (a.Lk + 63) / 64);
+    a.partial = partial;
+    dim3 grid(qtiles, nbatch, a.nsplit), block(256);
+    {
+        ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
+        if (mode == 0)
+            hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((gsv_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && a.nsplit > 1) {
+        const long total = (long)nbatch * a.Lq;
+        hipLaunchKernelGGL((gsv_combine_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, nbatch);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t um_global_corr_workspace_bytes(int batch, int tokens, int channels, int mode) {
     if (batch <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
-    return 2 * align256(planes_bytes((long)batch * tokens, mode)) + align256((size_t)tokens * 2 * sizeof(float));
+    return 2 * align256(planes_bytes((long)batch * tokens, mode)) + align256((size_t)tokens * 2 * sizeof(float)) +
+           align256((size_t)GSV_MAX_SPLIT * batch * tokens * 4 * sizeof(float));
 }
 
 static int check_common(const void* p0, const void* p1, const void* p2, int batch, int h, int w, int channels,
@@ -237,6 +374,10 @@ static int check_common(const void* p0, const void* p1, const void* p2, int batc
         um_set_error("workspace too small: %zu bytes given, %zu needed", ws_bytes, need);
         return -3;
     }
+    if ((long)batch * h * w * UM_CHANNELS * 2 >= (1L << 32)) {
+        um_set_error("batch*tokens = %ld exceeds the 32-bit plane addressing of this kernel", (long)batch * h * w);
+        return -4;
+    }
     return 0;
 }
 
@@ -252,6 +393,7 @@ extern "C" int um_global_corr_softmax_flow(const float* f0, const float* f1, flo
     unsigned short* p0 = (unsigned short*)ws;
     unsigned short* p1 = (unsigned short*)(ws + pb);
     float* grid = (float*)(ws + 2 * pb);
+    float* partial = (float*)(ws + 2 * pb + align256((size_t)L * 2 * sizeof(float)));
     hipError_t e;
     if ((e = launch_split_planes(f0, p0, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
     if ((e = launch_split_planes(f1, p1, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
@@ -270,12 +412,12 @@ extern "C" int um_global_corr_softmax_flow(const float* f0, const float* f1, flo
     a.qp = p0;
     a.kp = p1;
     a.out = flow;
-    if ((e = launch_gsv<2, false>(a, batch, mode, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_gsv<2, false>(a, batch, mode, partial, stream)) != hipSuccess) return (int)e;
     if (bidir) {   // backward flow: softmax over the other axis of the same correlation (matching.py:23-27)
         a.qp = p1;
         a.kp = p0;
         a.out = flow + (long)batch * 2 * L;
-        if ((e = launch_gsv<2, false>(a, batch, mode, stream)) != hipSuccess) return (int)e;
+        if ((e = launch_gsv<2, false>(a, batch, mode, partial, stream)) != hipSuccess) return (int)e;
     }
     return 0;
 }
@@ -310,7 +452,7 @@ extern "C" int um_global_corr_softmax_stereo(const float* f0, const float* f1, f
     a.scale_log2 = UM_LOG2E / sqrtf((float)channels);
     a.alpha = -1.f;                     // disparity = x - E[x']   (matching.py:147-149)
     a.beta = 1.f;
-    if ((e = launch_gsv<1, true>(a, batch * h, mode, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_gsv<1, true>(a, batch * h, mode, nullptr, stream)) != hipSuccess) return (int)e;
     return 0;
 }
 
@@ -329,6 +471,7 @@ extern "C" int um_prop_global_attn(const float* q, const float* k, const float* 
     const size_t pb = align256(planes_bytes(batch * L, mode));
     unsigned short* pq = (unsigned short*)ws;
     unsigned short* pk = (unsigned short*)(ws + pb);
+    float* partial = (float*)(ws + 2 * pb + align256((size_t)L * 2 * sizeof(float)));
     hipError_t e;
     if ((e = launch_split_planes(q, pq, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
     if ((e = launch_split_planes(k, pk, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
@@ -345,8 +488,8 @@ extern "C" int um_prop_global_attn(const float* q, const float* k, const float* 
     a.alpha = 1.f;
     a.beta = 0.f;
     if (value_channels == 2)
-        e = launch_gsv<2, false>(a, batch, mode, stream);
+        e = launch_gsv<2, false>(a, batch, mode, partial, stream);
     else
-        e = launch_gsv<1, false>(a, batch, mode, stream);
+        e = launch_gsv<1, false>(a, batch, mode, partial, stream);
     return (int)e;
 }
