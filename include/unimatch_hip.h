@@ -58,7 +58,8 @@ const char* um_last_error_string(void);
 #define UM_K_PROP_LOCAL 5    /* prop_local_attn_kernel                                                   */
 #define UM_K_DEPTH_CORR 6    /* depth_corr_softmax_kernel                                                */
 #define UM_K_LINEAR 7        /* linear_kernel (um_linear_fwd)                                            */
-#define UM_K_COUNT 8
+#define UM_K_INSTANCE_NORM 8 /* instance_norm_kernel (um_instance_norm_fwd)                              */
+#define UM_K_COUNT 9
 int um_timing_enable(int on);
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
@@ -168,6 +169,17 @@ int um_prop_local_attn(const float* q, const float* k, const float* value, float
 int um_depth_corr_softmax(const float* f0, const float* f1, const float* cam, const float* candidates,
                           float* out, int batch, int h, int w, int channels, int num_candidates,
                           int from_argmax, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder helper (outside the hot path of SURVEY.md section 8; added because the element-wise tail of the CNN encoder
+ * had become the largest non-convolution cost):  fused InstanceNorm2d(affine=False) + ReLU (+ shortcut + ReLU),
+ *   t = (x - mean) * rsqrt(var + eps) per (image, channel) plane; relu != 0: t = max(t, 0);
+ *   shortcut != NULL: t = max(t + shortcut, 0).
+ * Replaces nn.InstanceNorm2d + nn.ReLU (+ residual add + ReLU) of unimatch/backbone.py:7-36.
+ * x, shortcut, y: [planes, hw] fp32 contiguous (NCHW with planes = N*C, hw = H*W, hw % 4 == 0).
+ * ------------------------------------------------------------------------------------------- */
+int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long planes, int hw, float eps,
+                         int relu, void* stream);
 
 #ifdef __cplusplus
 }

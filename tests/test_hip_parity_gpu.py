@@ -366,3 +366,13 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         assert err(_to_map(o0, h, w), want0)[0] < 2e-4, tag
         assert err(_to_map(o1, h, w), want1)[0] < 2e-4, tag
         assert err(_to_map(o0, h, w), g[f'{tag}.o0'])[0] < 4e-4, tag
+
+
+def test_fused_instance_norm(ops):
+    x = rnd(80, 3, 5, 24, 36, scale=3.0) + 1.5
+    sc = rnd(81, 3, 5, 24, 36)
+    want = torch.nn.functional.instance_norm(x.double())
+    assert err(ops.instance_norm(x.to(DEV), relu=False), want)[0] < 2e-6
+    assert err(ops.instance_norm(x.to(DEV), relu=True), want.clamp(min=0))[0] < 2e-6
+    got = ops.instance_norm(x.to(DEV), relu=True, shortcut=sc.to(DEV))
+    assert err(got, (want.clamp(min=0) + sc.double()).clamp(min=0))[0] < 2e-6

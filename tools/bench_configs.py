@@ -1,0 +1,32 @@
+"""Run the five BASELINE.json configs at their full sizes on one GPU (diagnostic; bench.py measures configs[1])."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from unimatch_amd import UniMatch
+from unimatch_amd.synth import CONFIGS, synth_camera, synth_images, synth_state_dict
+RUNS = [  # (label, config, batch, H, W)
+    ('cfg1 GMFlow-s1 1x320x448', 'gmflow_s1', 1, 320, 448),
+    ('cfg2 GMFlow-s1 8x512x768', 'gmflow_s1', 8, 512, 768),
+    ('cfg3 GMStereo-s2-rr3 4x512x960', 'gmstereo_s2_rr3', 4, 512, 960),
+    ('cfg4 GMFlow-s2-rr6 4x512x768 (per-GPU share of B=32)', 'gmflow_s2_rr6', 4, 512, 768),
+    ('cfg5 GMDepth-s1 16x480x640', 'gmdepth_s1', 16, 480, 640),
+]
+for label, name, b, hh, ww in RUNS:
+    ck, fk = CONFIGS[name]
+    model = UniMatch(**ck).eval()
+    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
+    model = model.cuda()
+    i0, i1 = synth_images(b, hh, ww, seed=3, kind='shift', normalized=(fk['task'] != 'flow'))
+    kw = dict(fk)
+    if fk['task'] == 'depth':
+        k, pose = synth_camera(b, hh, ww)
+        kw.update(intrinsics=k.cuda(), pose=pose.cuda())
+    i0, i1 = i0.cuda(), i1.cuda()
+    for _ in range(2):
+        out = model(i0, i1, **kw)['flow_preds'][0]
+    torch.cuda.synchronize(); t = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        out = model(i0, i1, **kw)['flow_preds'][0]
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+    print(f'{label:58s} out {tuple(out.shape)} finite={bool(torch.isfinite(out).all())}  {dt*1e3:8.2f} ms/step  {b/dt:8.1f} pairs/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB', flush=True)
+    del model, out; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()

@@ -25,7 +25,11 @@ class _Residual(nn.Module):
             self.norm3 = nn.InstanceNorm2d(cout)
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride), self.norm3)
 
-    def forward(self, x):
+    def forward(self, x, ops=None):
+        if ops is not None:            # fused InstanceNorm + ReLU (+ shortcut + ReLU) kernels
+            y = ops.instance_norm(self.conv1(x), relu=True)
+            sc = x if self.downsample is None else ops.instance_norm(self.downsample[0](x), relu=False)
+            return ops.instance_norm(self.conv2(y), relu=True, shortcut=sc.contiguous())
         y = F.relu(self.norm1(self.conv1(x)))
         y = F.relu(self.norm2(self.conv2(y)))
         return F.relu((x if self.downsample is None else self.downsample(x)) + y)
@@ -65,7 +69,16 @@ class CNNEncoder(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
 
-    def forward(self, x):
-        x = F.relu(self.norm1(self.conv1(x)))
-        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+    def forward(self, x, ops=None):
+        """``ops``: a backend offering ``instance_norm`` (HipOps) fuses the normalisation / activation tail of
+        every convolution; ``None`` keeps the stock PyTorch modules (CPU tests)."""
+        if ops is not None and getattr(ops, 'fused_tail', False) and x.is_cuda:
+            x = ops.instance_norm(self.conv1(x), relu=True)
+            for layer in (self.layer1, self.layer2, self.layer3):
+                for block in layer:
+                    x = block(x, ops)
+            x = self.conv2(x)
+        else:
+            x = F.relu(self.norm1(self.conv1(x)))
+            x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return self.trident_conv(x) if self.num_branch > 1 else [x]       # high -> low resolution

@@ -313,7 +313,7 @@ class UniMatch(nn.Module):
                 mean = torch.tensor(_IMAGENET_MEAN, device=dev).view(1, 3, 1, 1)
                 std = torch.tensor(_IMAGENET_STD, device=dev).view(1, 3, 1, 1)
                 img0, img1 = (img0 / 255. - mean) / std, (img1 / 255. - mean) / std
-            feats = self.backbone(torch.cat([img0, img1], 0))[::-1]         # low -> high resolution
+            feats = self.backbone(torch.cat([img0, img1], 0), ops)[::-1]    # low -> high resolution
             nb = img0.shape[0]
             flow, pred = None, None
             for s in range(self.num_scales):

@@ -180,6 +180,22 @@ class HipOps:
         _abi.check(code, 'um_window_attn_planes_fwd')
         return out
 
+    # ------------------------------------------------------------------ encoder helper (outside the hot path)
+    def instance_norm(self, x, relu=True, shortcut=None, eps=1e-5):
+        """Fused InstanceNorm2d(affine=False) [+ ReLU] [+ shortcut, ReLU] on a contiguous NCHW fp32 map."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+            raise ValueError('instance_norm: expected a contiguous CUDA float32 NCHW tensor')
+        if shortcut is not None and not (shortcut.shape == x.shape and shortcut.is_contiguous()
+                                         and shortcut.dtype == torch.float32):
+            raise ValueError('instance_norm: shortcut must match x')
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        code = self._launch('instance_norm', lambda: self.lib.um_instance_norm_fwd(
+            _ptr(x), _ptr(shortcut) if shortcut is not None else None, _ptr(y), n * c, h * w, float(eps),
+            int(bool(relu)), _stream()))
+        _abi.check(code, 'um_instance_norm_fwd')
+        return y
+
     # ------------------------------------------------------------------ global matching
     def global_corr_softmax_flow(self, f0, f1, h, w, bidir=False):
         b, l, c = f0.shape
