@@ -376,3 +376,20 @@ def test_fused_instance_norm(ops):
     assert err(ops.instance_norm(x.to(DEV), relu=True), want.clamp(min=0))[0] < 2e-6
     got = ops.instance_norm(x.to(DEV), relu=True, shortcut=sc.to(DEV))
     assert err(got, (want.clamp(min=0) + sc.double()).clamp(min=0))[0] < 2e-6
+
+
+def test_hip_graph_replay_matches_eager():
+    """Whole forward captured into a HIP graph: bitwise equal to the eager result, also after new inputs."""
+    from unimatch_amd.graph import GraphedUniMatch
+    ck, fk = CONFIGS['gmflow_s1']
+    model = UniMatch(**ck).eval()
+    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}))
+    model = model.to(DEV)
+    graphed = GraphedUniMatch(model)
+    for seed in (5, 6):
+        i0, i1 = synth_images(2, 64, 96, seed=seed, kind='shift')
+        i0, i1 = i0.to(DEV), i1.to(DEV)
+        want = model(i0, i1, **fk)['flow_preds'][0]
+        got = graphed(i0, i1, **fk)['flow_preds'][0]
+        assert torch.equal(got, want)
+    assert len(graphed._graphs) == 1 and all(v is not False for v in graphed._graphs.values())

@@ -1,0 +1,67 @@
+"""HIP-graph replay of the whole forward.
+
+The forward of ``UniMatch`` is a fixed sequence of ~200 kernel launches with no host synchronisation (the
+reference's per-layer device->host sync, transformer.py:55, is gone), so for a fixed input shape it can be captured
+once and replayed: at small batch the step is launch-bound (about 10 us of host time per launch), which is the
+regime of the reference's own evaluation protocol (batch 1).  ``GraphedUniMatch(model)`` behaves like the model;
+each distinct (shapes, keyword arguments) combination is captured on first use.
+"""
+import warnings
+
+import torch
+
+
+def _freeze(v):
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    if torch.is_tensor(v):
+        return ('tensor', tuple(v.shape), str(v.dtype))
+    return v
+
+
+class GraphedUniMatch(torch.nn.Module):
+    def __init__(self, model, warmup=2, clone_output=True):
+        super().__init__()
+        self.model = model
+        self.warmup = warmup
+        self.clone_output = clone_output
+        self._graphs = {}
+
+    def _capture(self, img0, img1, kw):
+        static = {'img0': img0.clone(), 'img1': img1.clone(),
+                  'kw': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up: position tables, weight planes, MIOpen solver selection
+            for _ in range(self.warmup):
+                self.model(static['img0'], static['img1'], **static['kw'])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static['out'] = self.model(static['img0'], static['img1'], **static['kw'])['flow_preds'][0]
+        static['graph'] = graph
+        return static
+
+    def forward(self, img0, img1, **kw):
+        if not img0.is_cuda:
+            return self.model(img0, img1, **kw)
+        key = (tuple(img0.shape), tuple(img1.shape), str(img0.dtype), tuple(sorted((k, _freeze(v)) for k, v in kw.items())))
+        entry = self._graphs.get(key)
+        if entry is None:
+            try:
+                entry = self._capture(img0, img1, kw)
+            except RuntimeError as exc:          # an op that cannot be captured (e.g. a library call that syncs)
+                warnings.warn(f'HIP graph capture failed ({exc}); running eagerly for this configuration')
+                entry = False
+            self._graphs[key] = entry
+        if entry is False:
+            return self.model(img0, img1, **kw)
+        entry['img0'].copy_(img0)
+        entry['img1'].copy_(img1)
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                entry['kw'][k].copy_(v)
+        entry['graph'].replay()
+        out = entry['out']
+        return {'flow_preds': [out.clone() if self.clone_output else out]}

@@ -285,6 +285,22 @@ class UniMatch(nn.Module):
             self._pos_cache[key] = tab.to(device)
         return self._pos_cache[key]
 
+    def _constants(self, device):
+        """ImageNet mean / std on ``device``, uploaded once (keeps the forward free of host->device copies so that
+        it can be captured into a HIP graph)."""
+        key = ('imagenet', str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = (torch.tensor(_IMAGENET_MEAN).view(1, 3, 1, 1).to(device),
+                                    torch.tensor(_IMAGENET_STD).view(1, 3, 1, 1).to(device))
+        return self._pos_cache[key]
+
+    def _depth_candidates(self, lo, hi, n, device):
+        """Inverse-depth candidates: computed on the CPU exactly as the reference does (unimatch.py:187), cached."""
+        key = ('cand', float(lo), float(hi), int(n), str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = torch.linspace(lo, hi, n).float().to(device).contiguous()
+        return self._pos_cache[key]
+
     def _upsample(self, flow2, f0_map, is_depth=False):
         mask = self.upsampler(torch.cat([flow2, f0_map], 1))
         return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
@@ -310,8 +326,7 @@ class UniMatch(nn.Module):
 
         with torch.no_grad():
             if task == 'flow':                  # stereo / depth loaders normalise already (unimatch.py:122-124)
-                mean = torch.tensor(_IMAGENET_MEAN, device=dev).view(1, 3, 1, 1)
-                std = torch.tensor(_IMAGENET_STD, device=dev).view(1, 3, 1, 1)
+                mean, std = self._constants(dev)
                 img0, img1 = (img0 / 255. - mean) / std, (img1 / 255. - mean) / std
             feats = self.backbone(torch.cat([img0, img1], 0), ops)[::-1]    # low -> high resolution
             nb = img0.shape[0]
@@ -344,7 +359,7 @@ class UniMatch(nn.Module):
 
                 # ---- matching layer
                 if task == 'depth':
-                    cand = torch.linspace(min_depth, max_depth, num_depth_candidates).to(dev).float()
+                    cand = self._depth_candidates(min_depth, max_depth, num_depth_candidates, dev)
                     f0c, f1c, kc, pc = tok0, tok1, k_cur, pose
                     if pred_bidir_depth:
                         f0c, f1c = torch.cat([tok0, tok1], 0), torch.cat([tok1, tok0], 0)
