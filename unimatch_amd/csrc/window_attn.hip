@@ -26,11 +26,6 @@
 #include "common.h"
 #include "planes.h"
 
-// Diagnostic ablations (tools/ablate_attn.sh builds variant libraries with -DUM_ABL=<bits>; never set in the product build)
-//   1 no exp/convert (softmax VALU)   2 no PV MFMAs   4 no QK MFMAs   8 no LDS-DMA in the loop   16 no barrier in the loop
-#ifndef UM_ABL
-#define UM_ABL 0
-#endif
 // -DUM_TRACE: wave 0 / lane 0 of every 37th workgroup stamps s_memtime at section boundaries of its first 24 tiles
 // into the buffer given to um_debug_set_trace() (diagnostics only; tools/trace_attn.py).
 #ifdef UM_TRACE
@@ -247,7 +242,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto tile = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         UM_STAMP(0);
-        const bool staging = t + 1 < ntiles && !((UM_ABL & 8) && t > 0);
+        const bool staging = t + 1 < ntiles;
         unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
         if (staging) stage_prepare(t + 1, nxt);
         const unsigned char* kb = lds + SLOT * BUF;
@@ -272,11 +267,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks + 2]);
                 }
                 if (staging && (ks * NPIECE) % 8 == 0) stage_piece(ks * NPIECE / 8, nxt);
-                if (UM_ABL & 4) {
-                    asm volatile("" : "+v"(fh[ks % 3]));
-                    if (NS == 2) asm volatile("" : "+v"(fl[ks % 3]));
-                    continue;
-                }
                 if (NS == 2) {
                     sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
                     sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
@@ -311,15 +301,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float mx = sc[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-#ifdef UM_OLDMAX
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-#else
         {   // max with the partner lane (l ^ 32) without touching LDS
             float u, v2;
             half_wave_pair(mx, u, v2);
             mx = fmaxf(u, v2);
         }
-#endif
         m = fmaxf(m, mx);
         // Lazy, exact rescale.  The exponent offset M is an integer (every rescale factor is a power of two) and
         // is allowed to lag the true running max by up to LAG: then p <= 2^(LAG + PSHIFT) = 2^15 still fits fp16,
@@ -340,7 +326,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const float mc = M + (float)PSHIFT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = (UM_ABL & 1) ? sc[r] : fast_exp2(__builtin_fmaf(sc[r], c, mc));
+            const float p = fast_exp2(__builtin_fmaf(sc[r], c, mc));
             sc[r] = p;
             l += p;
         }
@@ -356,11 +342,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float p0 = sc[r0 + 2 * j], p1 = sc[r0 + 2 * j + 1];
-                if (UM_ABL & 1) {
-                    wh[j] = __builtin_bit_cast(unsigned, p0);
-                    wl[j] = __builtin_bit_cast(unsigned, p1);
-                    continue;
-                }
                 wh[j] = T::pack2(p0, p1);
                 if (NS == 2) {
                     const f32x2 hh = T::unpack2(wh[j]);
@@ -403,18 +384,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) i16x4*)(va + PLANE + 4 * 256));
                     vl = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (UM_ABL & 2) {
-                        asm volatile("" : "+v"(vl), "+v"(pf[NS - 1][ks]));
-                    } else {
-                        o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
-                        o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
-                    }
+                    o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
+                    o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
                 }
-                if (UM_ABL & 2) {
-                    asm volatile("" : "+v"(vh), "+v"(pf[0][ks]));
-                } else {
-                    o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
-                }
+                o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
             }
         }
         {   // transpose reads two (k-step, d-tile) groups ahead of the MFMAs
@@ -430,8 +403,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         UM_STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed in LDS
         UM_STAMP(5);
-        if (!(UM_ABL & 16))
-            __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
+        __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
     for (int t = 0; t < ntiles; t += 2) {
@@ -444,15 +416,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
     // ---- normalise and scatter back to the original token positions -----------------------------------------
     float lt;
-#ifdef UM_OLDSUM
-    lt = l + __shfl_xor(l, 32);
-#else
     {
         float u, v2;
         half_wave_pair(l, u, v2);
         lt = u + v2;
     }
-#endif
     const float inv = 1.0f / lt;
     if (tq < a.n) {
         float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
