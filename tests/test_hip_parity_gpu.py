@@ -368,9 +368,11 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         assert err(_to_map(o0, h, w), g[f'{tag}.o0'])[0] < 4e-4, tag
 
 
-def test_fused_instance_norm(ops):
-    x = rnd(80, 3, 5, 24, 36, scale=3.0) + 1.5
-    sc = rnd(81, 3, 5, 24, 36)
+@pytest.mark.parametrize('hw', [(24, 36), (64, 96), (256, 384), (400, 320)])
+def test_fused_instance_norm(ops, hw):
+    """(400, 320) exceeds the register-resident variant (24 float4 x 1024 threads) and takes the streaming kernel."""
+    x = rnd(80, 2, 3, *hw, scale=3.0) + 1.5
+    sc = rnd(81, 2, 3, *hw)
     want = torch.nn.functional.instance_norm(x.double())
     assert err(ops.instance_norm(x.to(DEV), relu=False), want)[0] < 2e-6
     assert err(ops.instance_norm(x.to(DEV), relu=True), want.clamp(min=0))[0] < 2e-6

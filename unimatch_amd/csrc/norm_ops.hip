@@ -73,6 +73,72 @@ __global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restr
     }
 }
 
+// Register-resident variant: the whole (image, channel) plane lives in the workgroup's registers (up to 1024
+// threads x EPT float4), so the activation is read from HBM exactly once -- the planes of the early encoder stages
+// (393 KB each, ~1000 of them in flight) do not survive in L2 between the sweeps of the streaming kernel above.
+template <int EPT>
+__global__ __launch_bounds__(1024) void instance_norm_reg_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ shortcut,
+                                                                 float* __restrict__ y, int hw, float eps, int relu) {
+    __shared__ float red[2][16];
+    const long base = (long)blockIdx.x * hw;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + base);
+    const int n4 = hw >> 2, tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    f32x4 v[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nthr;
+        v[e] = i < n4 ? xp[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+    auto block_total = [&](float val, int slot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
+        if (lane == 0) red[slot][wave] = val;
+        __syncthreads();
+        float t = 0.f;
+        for (int w2 = 0; w2 < nwave; ++w2) t += red[slot][w2];
+        return t;
+    };
+    const float mean = block_total(s, 0) / (float)hw;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nthr;
+        if (i < n4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[e][j] - mean;
+                q = __builtin_fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_total(q, 1) / (float)hw + eps);
+    const f32x4* sp = shortcut ? reinterpret_cast<const f32x4*>(shortcut + base) : nullptr;
+    f32x4* yp = reinterpret_cast<f32x4*>(y + base);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * nthr;
+        if (i < n4) {
+            f32x4 o = v[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (o[j] - mean) * rstd;
+                if (relu) o[j] = fmaxf(o[j], 0.f);
+            }
+            if (sp) {
+                const f32x4 r = sp[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j] + r[j], 0.f);
+            }
+            yp[i] = o;
+        }
+    }
+}
+
 extern void um_set_error(const char* fmt, ...);
 
 extern "C" int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long planes, int hw, float eps,
@@ -87,7 +153,16 @@ extern "C" int um_instance_norm_fwd(const float* x, const float* shortcut, float
         return -4;
     }
     ScopedKernelTimer timer(UM_K_INSTANCE_NORM, (hipStream_t)stream);
-    hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, shortcut, y, hw,
-                       eps, relu);
+    constexpr int EPT = 24;
+    const int n4 = hw >> 2;
+    if (n4 <= EPT * 1024) {
+        int threads = ((n4 + EPT - 1) / EPT + 63) / 64 * 64;
+        if (threads < 64) threads = 64;
+        hipLaunchKernelGGL((instance_norm_reg_kernel<EPT>), dim3((unsigned)planes), dim3(threads), 0, (hipStream_t)stream, x,
+                           shortcut, y, hw, eps, relu);
+    } else {
+        hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, shortcut, y,
+                           hw, eps, relu);
+    }
     return (int)hipGetLastError();
 }
