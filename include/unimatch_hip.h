@@ -59,7 +59,8 @@ const char* um_last_error_string(void);
 #define UM_K_DEPTH_CORR 6    /* depth_corr_softmax_kernel                                                */
 #define UM_K_LINEAR 7        /* linear_kernel (um_linear_fwd)                                            */
 #define UM_K_INSTANCE_NORM 8 /* instance_norm_kernel (um_instance_norm_fwd)                              */
-#define UM_K_COUNT 9
+#define UM_K_CONVEX_UPSAMPLE 9 /* convex_upsample_kernel (um_convex_upsample)                            */
+#define UM_K_COUNT 10
 int um_timing_enable(int on);
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
@@ -169,6 +170,16 @@ int um_prop_local_attn(const float* q, const float* k, const float* value, float
 int um_depth_corr_softmax(const float* f0, const float* f1, const float* cam, const float* candidates,
                           float* out, int batch, int h, int w, int channels, int num_candidates,
                           int from_argmax, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RAFT convex upsampling (SURVEY.md 8(f) "next" row): softmax over the 9 neighbours of each of factor^2 sub-pixels,
+ * weighted sum of the 3x3 (zero padded) neighbourhood of mult * flow, pixel shuffle.  Replaces
+ * upsample_flow_with_mask (unimatch/utils.py:134-152).  flow: [B, V, h, w] (V = 1 | 2), mask: [B, 9*factor^2, h, w]
+ * (channel = k*factor^2 + fy*factor + fx), up: [B, V, factor*h, factor*w]; mult = 1 if is_depth else factor;
+ * factor 4 or 8.
+ * ------------------------------------------------------------------------------------------- */
+int um_convex_upsample(const float* flow, const float* mask, float* up, int batch, int channels, int h, int w,
+                       int factor, int is_depth, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder helper (outside the hot path of SURVEY.md section 8; added because the element-wise tail of the CNN encoder

@@ -395,3 +395,14 @@ def test_hip_graph_replay_matches_eager():
         got = graphed(i0, i1, **fk)['flow_preds'][0]
         assert torch.equal(got, want)
     assert len(graphed._graphs) == 1 and all(v is not False for v in graphed._graphs.values())
+
+
+@pytest.mark.parametrize('cfg', [(8, 2, False), (4, 2, False), (8, 1, True), (4, 1, False)])
+def test_convex_upsample(ops, cfg):
+    factor, v, is_depth = cfg
+    b, h, w = 2, 12, 20
+    flow = rnd(90, b, v, h, w, scale=5.0)
+    mask = rnd(91, b, 9 * factor * factor, h, w, scale=2.0)
+    want = om.convex_upsample(flow.double(), mask.double(), factor, is_depth=is_depth)
+    got = ops.convex_upsample(flow.to(DEV), mask.to(DEV), factor, is_depth)
+    assert got.shape == want.shape and err(got, want)[0] < 2e-6 * max(1.0, want.abs().max().item())

@@ -301,9 +301,15 @@ class UniMatch(nn.Module):
             self._pos_cache[key] = torch.linspace(lo, hi, n).float().to(device).contiguous()
         return self._pos_cache[key]
 
+    def _convex(self, flow2, mask, is_depth=False):
+        ops = self.ops
+        if hasattr(ops, 'convex_upsample') and flow2.is_cuda and self.upsample_factor in (4, 8):
+            return ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth)
+        return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
+
     def _upsample(self, flow2, f0_map, is_depth=False):
         mask = self.upsampler(torch.cat([flow2, f0_map], 1))
-        return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
+        return self._convex(flow2, mask, is_depth=is_depth)
 
     # ------------------------------------------------------------------ forward
     def forward(self, img0, img1, attn_type=None, attn_splits_list=None, corr_radius_list=None,
@@ -438,7 +444,7 @@ class UniMatch(nn.Module):
                             pred = self._upsample(pad, f0_map, is_depth=True).clamp(
                                 min=min_depth, max=max_depth)[:, :1]
                         else:
-                            pred = convex_upsample(flow, up_mask, self.upsample_factor)
+                            pred = self._convex(flow, up_mask)
             if task == 'stereo':
                 pred = pred.squeeze(1)
             if task == 'depth':

@@ -180,6 +180,20 @@ class HipOps:
         _abi.check(code, 'um_window_attn_planes_fwd')
         return out
 
+    # ------------------------------------------------------------------ convex upsampling (SURVEY 8(f) "next" row)
+    def convex_upsample(self, flow, mask, factor, is_depth=False):
+        """RAFT convex upsampling of ``flow [B,V,h,w]`` with ``mask [B,9*factor^2,h,w]`` -> ``[B,V,factor*h,factor*w]``."""
+        b, v, h, w = flow.shape
+        if not (flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32
+                and tuple(mask.shape) == (b, 9 * factor * factor, h, w)):
+            raise ValueError(f'convex_upsample: bad shapes flow {tuple(flow.shape)} mask {tuple(mask.shape)}')
+        flow, mask = flow.contiguous(), mask.contiguous()
+        up = torch.empty((b, v, factor * h, factor * w), dtype=torch.float32, device=flow.device)
+        code = self._launch('convex_upsample', lambda: self.lib.um_convex_upsample(
+            _ptr(flow), _ptr(mask), _ptr(up), b, v, h, w, factor, int(bool(is_depth)), _stream()))
+        _abi.check(code, 'um_convex_upsample')
+        return up
+
     # ------------------------------------------------------------------ encoder helper (outside the hot path)
     def instance_norm(self, x, relu=True, shortcut=None, eps=1e-5):
         """Fused InstanceNorm2d(affine=False) [+ ReLU] [+ shortcut, ReLU] on a contiguous NCHW fp32 map."""
