@@ -219,6 +219,35 @@ def gold_e2e():
     save('e2e', **out)
 
 
+
+
+
+# ----------------------------------------------------------------------------------------------- on-disk formats
+def gold_formats():
+    """Bytes written by the reference's own writers (cv2 is not installed here: frame_utils only needs the import
+    to succeed for writeFlow / readFlow, so an empty stub module stands in)."""
+    import tempfile
+    import types
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    from utils import frame_utils, file_io
+    from utils.utils import InputPadder
+    flow = rnd(500, 7, 9, 2, scale=20.0).numpy()
+    disp = (rnd(501, 6, 5).abs() * 30).numpy().astype(np.float32)
+    out = {'flow': flow, 'disp': disp}
+    with tempfile.TemporaryDirectory() as d:
+        frame_utils.writeFlow(os.path.join(d, 'a.flo'), flow)
+        out['flo_bytes'] = np.frombuffer(open(os.path.join(d, 'a.flo'), 'rb').read(), np.uint8)
+        file_io.write_pfm(os.path.join(d, 'a.pfm'), disp)
+        out['pfm_bytes'] = np.frombuffer(open(os.path.join(d, 'a.pfm'), 'rb').read(), np.uint8)
+    for i, (hh, ww, mode, pf) in enumerate(((436, 1024, 'sintel', 16), (375, 1242, 'kitti', 32), (64, 96, 'sintel', 8))):
+        x = rnd(510 + i, 1, 3, hh, ww)
+        p = InputPadder(x.shape, mode=mode, padding_factor=pf)
+        y = p.pad(x)[0]
+        out[f'pad{i}.meta'] = np.array([hh, ww, pf, y.shape[-2], y.shape[-1]] + list(p._pad))
+        out[f'pad{i}.sum'] = np.array([y.double().sum().item()])
+    save('formats', **out)
+
+
 if __name__ == '__main__':
     gold_position()
     gold_attention()
@@ -226,3 +255,4 @@ if __name__ == '__main__':
     gold_matching()
     gold_propagation()
     gold_e2e()
+    gold_formats()
