@@ -47,6 +47,9 @@ def parse():
     return ap.parse_args()
 
 
+UM_K_COUNT = 10      # include/unimatch_hip.h
+
+
 def collect(lib, kid):
     ms, n = ctypes.c_double(0), ctypes.c_int(0)
     lib.um_timing_collect(kid, ctypes.byref(ms), ctypes.byref(n))
@@ -94,7 +97,7 @@ def main():
         pred = step()
     torch.cuda.synchronize()
     lib.um_timing_enable(1)
-    for kid in range(7):
+    for kid in range(UM_K_COUNT):
         collect(lib, kid)
     if distributed:
         dist.barrier()
@@ -210,7 +213,7 @@ def main():
                                'correlation + global propagation, random-init weights',
                    'per_gpu_batch': b, 'global_batch': world * b, 'precision': args.precision,
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; '
-                                     'linears/FFN/convs fp32 on PyTorch-ROCm',
+                                     'Transformer linears/LN/GELU fused in the same split-fp16 MFMA kernels; convs fp32 (MIOpen)',
                    'parallelism': f'dp{world} (batch-sharded, all-gather of predictions)' if distributed else 'single GPU'},
         'roofline': roof, 'roofline_global_corr': roof2,
         'split_planes_ms_per_step': round(split_ms / args.steps, 3) if split_n else None,

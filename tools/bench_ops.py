@@ -1,7 +1,7 @@
 """Micro-benchmark of the HIP entry points at BASELINE sizes (GPU box).  Kernel time comes from the library's
 own hipEvents (um_timing_*), so split/convert pre-passes are reported separately from the main kernels.
 
-    python tools/bench_ops.py [attn] [gsv] [local] [--iters N] [--precision exact|fast] [--quick]
+    python tools/bench_ops.py [attn] [gsv] [local] [linear] [--iters N] [--precision exact|fast] [--quick]
 """
 import ctypes
 import os
@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 from unimatch_amd import _abi  # noqa: E402
 from unimatch_amd.ops import HipOps  # noqa: E402
 
-KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr']
+KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr', 'linear',
+          'instance_norm', 'convex_upsample']
 PEAK = 2.5e15
 
 
@@ -50,7 +51,7 @@ def main():
     args = sys.argv[1:]
     iters = int(args[args.index('--iters') + 1]) if '--iters' in args else 10
     prec = args[args.index('--precision') + 1] if '--precision' in args else 'exact'
-    what = [a for a in args if a in ('attn', 'gsv', 'local')] or ['attn', 'gsv', 'local']
+    what = [a for a in args if a in ('attn', 'gsv', 'local', 'linear')] or ['attn', 'gsv', 'local', 'linear']
     ops = HipOps(prec)
     lib = _abi.load()
     issued = 3.0 if prec == 'exact' else 1.0
@@ -75,6 +76,24 @@ def main():
             q, k, v = (torch.randn(S, h * w, C, device=dev, generator=g) * 2 for _ in range(3))
             run('attn cfg3-s1 S=8 128x240 1-D win30 shifted', lambda: ops.window_attention(q, k, v, h, w, 1, 30, 0, 15),
                 4.0 * S * h * w * 30 * C, lib, iters, 'window_attn', issued)
+    if 'linear' in what:
+        # the four GEMM shapes of one Transformer block at config 2: M = 2 streams x 8 pairs x 6144 tokens
+        M = 2 * 8 * 6144
+        x, y = (torch.randn(M, C, device=dev, generator=g) for _ in range(2))
+        wq, wk, wv, wm = (torch.randn(C, C, device=dev, generator=g) * 0.09 for _ in range(4))
+        w1 = torch.randn(8 * C, 2 * C, device=dev, generator=g) * 0.06
+        w2 = torch.randn(C, 8 * C, device=dev, generator=g) * 0.03
+        norm = torch.nn.LayerNorm(C).to(dev)
+        run('linear qkv   f32[M,128] -> planes[M,384]', lambda: ops.linear_planes(x, (wq, wk, wv)),
+            2.0 * M * C * 3 * C, lib, iters, 'linear', issued)
+        run('linear merge f32[M,128] -> LN f32[M,128]', lambda: ops.linear_ln(x, (wm,), norm),
+            2.0 * M * C * C, lib, iters, 'linear', issued)
+        run('linear ffn1  cat f32[M,256] -> gelu planes[M,1024]', lambda: ops.linear_planes(x, (w1,), a1=y, gelu=True),
+            2.0 * M * 2 * C * 8 * C, lib, iters, 'linear', issued)
+        hid, _, _ = ops.linear_planes(x, (w1,), a1=y, gelu=True)
+        run('linear ffn2  planes[M,1024] -> LN+res f32[M,128]',
+            lambda: ops.linear_ln(hid, (w2,), norm, residual=x, a_planes_k=8 * C),
+            2.0 * M * 8 * C * C, lib, iters, 'linear', issued)
     if 'gsv' in what:
         B, h, w = 8, 64, 96
         L = h * w

@@ -184,28 +184,43 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
         for (int r = 0; r < 16; ++r) acc[nt][r] *= a.out_scale;
 
     if (EPI == EPI_PLANES || EPI == EPI_GELU_PLANES) {
-        if (valid) {
-            unsigned short* ob = a.outp + (long)tok * a.N + n0 + 4 * half;
+        // The accumulator layout gives every lane 8-byte pieces of 32 different token rows: written directly that is
+        // 32 partial cache lines per store instruction (measured: the stores cost as much as the whole main loop).
+        // The tile goes through the idle staging ring instead -- every wave transposes its own 32 x 128 block, one
+        // 8 KB region per plane, 16-byte chunk c of row r at chunk c ^ (r & 15) -- and leaves as full 256-byte rows.
+        unsigned char* stg = lds + wave * 8192;                   // plane pl at + pl * 32768
+        const int tl = lane & 31;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i] = acc[nt][4 * g + i];
-                        if (EPI == EPI_GELU_PLANES) v[i] = gelu_erf(v[i]);
-                    }
-                    const unsigned h0 = T::pack2(v[0], v[1]), h1 = T::pack2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(ob + 32 * nt + 8 * g) = u32x2{h0, h1};
-                    if (NS == 2) {
-                        const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                        const unsigned l0 = T::pack2(v[0] - u0[0], v[1] - u0[1]);
-                        const unsigned l1 = T::pack2(v[2] - u1[0], v[3] - u1[1]);
-                        *reinterpret_cast<u32x2*>(ob + a.out_plane_stride + 32 * nt + 8 * g) = u32x2{l0, l1};
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[nt][4 * g + i];
+                    if (EPI == EPI_GELU_PLANES) v[i] = gelu_erf(v[i]);
                 }
-        }
+                unsigned char* p = stg + tl * 256 + (((4 * nt + g) ^ (tl & 15)) << 4) + 8 * half;
+                const unsigned h0 = T::pack2(v[0], v[1]), h1 = T::pack2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
+                if (NS == 2) {
+                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
+                    const unsigned l0 = T::pack2(v[0] - u0[0], v[1] - u0[1]);
+                    const unsigned l1 = T::pack2(v[2] - u1[0], v[3] - u1[1]);
+                    *reinterpret_cast<u32x2*>(p + 32768) = u32x2{l0, l1};
+                }
+            }
+        __builtin_amdgcn_wave_barrier();                          // same wave: LDS executes its accesses in order
+        const int row0 = m0 + 32 * wave;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = 4 * it + (lane >> 4), cch = lane & 15;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(stg + pl * 32768 + r * 256 + ((cch ^ (r & 15)) << 4));
+                if (row0 + r < a.M)
+                    *reinterpret_cast<u32x4*>(a.outp + pl * a.out_plane_stride + (long)(row0 + r) * a.N + n0 + 8 * cch) = d;
+            }
     } else {
         // LayerNorm over the N = 128 features of the token (two-pass in registers), optional residual
         float s1 = 0.f;
