@@ -60,7 +60,8 @@ const char* um_last_error_string(void);
 #define UM_K_LINEAR 7        /* linear_kernel (um_linear_fwd)                                            */
 #define UM_K_INSTANCE_NORM 8 /* instance_norm_kernel (um_instance_norm_fwd)                              */
 #define UM_K_CONVEX_UPSAMPLE 9 /* convex_upsample_kernel (um_convex_upsample)                            */
-#define UM_K_COUNT 10
+#define UM_K_FFN 10          /* ffn_kernel (um_ffn_fwd)                                                  */
+#define UM_K_COUNT 11
 int um_timing_enable(int on);
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
@@ -113,6 +114,15 @@ int um_linear_fwd(const float* a0, const float* a1, const void* a_planes, const 
                   int m, int n, int k, int wshift, int epilogue, void* out,
                   const float* gamma, const float* beta, const float* residual, float eps,
                   int mode, void* stream);
+
+/* Whole FFN of a Transformer layer in ONE kernel:
+ *     out = x + LayerNorm( W2 . gelu( W1 . [x | y] ) )          (unimatch/transformer.py:141-144, mlp :44-50)
+ * x (source, also the residual) and y (message): fp32 [M,128]; W1 [hidden, 256] and W2 [128, hidden] as
+ * um_weight_planes() planes with the same wshift; gamma/beta/eps: the layer's norm2.  The [M, hidden]
+ * activations stay on chip (the two-launch form um_linear_fwd(GELU_PLANES) + um_linear_fwd(LN) writes and reads them
+ * through HBM).  hidden: multiple of 32, >= 64.  out: fp32 [M,128], may not alias x or y. */
+int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+               int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs correlation + softmax + expected coordinate (flow).

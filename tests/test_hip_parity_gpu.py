@@ -348,6 +348,40 @@ def test_linear_layernorm_residual(ops):
     assert err(got, want)[0] < 5e-5
 
 
+@pytest.mark.parametrize('m,hidden', [(128, 1024), (333, 1024), (1000, 64), (4096 + 17, 512)])
+def test_fused_ffn_kernel(ops, m, hidden):
+    """um_ffn_fwd: x + LayerNorm(W2 . gelu(W1 . [x | y])) in one kernel against fp64 (ragged M, several hidden
+    widths), and against the two-launch form it replaces.  Tolerance: fp32-accurate (the planes carry 22 bits)."""
+    x, y = rnd(80, m, 128, scale=1.5), rnd(81, m, 128, scale=1.5)
+    w1 = rnd(82, hidden, 256, scale=0.08)
+    w2 = rnd(83, 128, hidden, scale=0.06)
+    norm = torch.nn.LayerNorm(128)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * rnd(84, 128))
+        norm.bias.copy_(0.1 * rnd(85, 128))
+    hid = torch.nn.functional.gelu(torch.cat([x, y], 1).double() @ w1.double().t())
+    want = x.double() + torch.nn.functional.layer_norm(hid @ w2.double().t(), (128,), norm.weight.double(),
+                                                       norm.bias.double(), norm.eps)
+    norm = norm.to(DEV)
+    xd, yd, w1d, w2d = x.to(DEV), y.to(DEV), w1.to(DEV), w2.to(DEV)
+    got = ops.ffn_ln(xd, yd, w1d, w2d, norm)
+    assert torch.isfinite(got).all()
+    assert err(got, want)[0] < 3e-5
+    if hidden % 128 == 0:                         # the two-launch form needs full 128-wide output tiles
+        hp_, _, nh = ops.linear_planes(xd, (w1d,), a1=yd, gelu=True)
+        two = ops.linear_ln(hp_, (w2d,), norm, residual=xd, a_planes_k=nh)
+        assert err(got, two)[0] < 2e-5
+
+
+def test_fused_ffn_rejects_bad_arguments(ops):
+    x = rnd(86, 64, 128).to(DEV)
+    norm = torch.nn.LayerNorm(128).to(DEV)
+    with pytest.raises(ValueError):
+        ops.ffn_ln(x, x, rnd(87, 1024, 128).to(DEV), rnd(88, 128, 1024).to(DEV), norm)     # W1 must be [hidden, 256]
+    with pytest.raises(Exception):
+        ops.ffn_ln(x, x, rnd(87, 48, 256).to(DEV), rnd(88, 128, 48).to(DEV), norm)         # hidden % 32 != 0
+
+
 def test_fused_layer_matches_unfused_layer(ops, golden):
     """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
     g = golden('transformer')
@@ -361,6 +395,10 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         f0, f1 = g[f'{tag}.f0'], g[f'{tag}.f1']
         h, w = f0.shape[-2:]
         o0, o1 = proto(ops, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
+        two = HipOps('exact')
+        two.fused_ffn = False                     # the two-launch FFN stays covered
+        t0, _ = proto(two, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
+        assert err(o0, t0)[0] < 2e-4, tag
         want0, want1 = hp.feature_transformer(f0.double(), f1.double(), {kk: v.double() for kk, v in sd.items()},
                                               attn_type, k)
         assert err(_to_map(o0, h, w), want0)[0] < 2e-4, tag

@@ -15,7 +15,7 @@ from unimatch_amd import _abi  # noqa: E402
 from unimatch_amd.ops import HipOps  # noqa: E402
 
 KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr', 'linear',
-          'instance_norm', 'convex_upsample']
+          'instance_norm', 'convex_upsample', 'ffn']
 PEAK = 2.5e15
 
 
@@ -94,6 +94,8 @@ def main():
         run('linear ffn2  planes[M,1024] -> LN+res f32[M,128]',
             lambda: ops.linear_ln(hid, (w2,), norm, residual=x, a_planes_k=8 * C),
             2.0 * M * 8 * C * C, lib, iters, 'linear', issued)
+        run('ffn fused    f32[M,128]x2 -> LN+res f32[M,128]', lambda: ops.ffn_ln(x, y, w1, w2, norm),
+            2.0 * M * 8 * C * 3 * C, lib, iters, 'ffn', issued)
     if 'gsv' in what:
         B, h, w = 8, 64, 96
         L = h * w

@@ -1,0 +1,362 @@
+// Fused Transformer FFN:  out = x + LayerNorm( W2 . gelu( W1 . [x | y] ) )                gfx950 / wave64 / MFMA
+//
+// replaces `source + norm2(mlp(cat([source, message])))` (unimatch/transformer.py:141-144; mlp = Linear(2C, 8C,
+// bias=False), GELU, Linear(8C, C, bias=False), :44-50).  The two-kernel version (linear.hip) writes the
+// [M, 8C] hidden activations to HBM as operand planes and reads them back: 2 x 403 MB per call at config 2 -- the
+// largest single HBM round trip of the model.  Here the hidden activations only ever
+// exist as MFMA accumulators and operand fragments of one wave.
+//
+// Decomposition ("flash" over the hidden dimension, same swapped products as the attention kernel):
+//   workgroup = 8 waves = 128 tokens; wave pair p (waves p and p + 4) owns tokens 32p .. 32p+31, lane = token.
+//   The hidden dimension is walked in slices of 32 units.  For slice j:
+//     phase A   S^T[32 hid][32 tok] = W1_j[32][256] . X^T          -- the pair splits K: role 0 multiplies the
+//               `x` half (k 0..127), role 1 the `y` half (k 128..255); this is what makes the token operand fit
+//               in registers (64 VGPRs per wave instead of 128) and it also makes the concatenation free;
+//     exchange  each wave keeps accumulator rows 0..15 and hands rows 16..31 to its partner through LDS (role 1
+//               reads W1 rows permuted by ^16, so that "rows 0..15" are hidden units 16..31 for it);
+//     GELU      on the wave's own 16 hidden units x 32 tokens, split into fp16 hi + lo, turned into B-operand
+//               fragments with v_permlane32_swap (no LDS);
+//     phase B   O^T[128 out][32 tok] += W2[:, own 16 hid] . H^T    -- the pair splits K again, each wave carries
+//               a partial O of all 128 outputs.
+//   Epilogue: role 1 hands its partial O to role 0 through LDS; role 0 applies LayerNorm + residual and stores.
+//
+// Weight slices stream through LDS by LDS-DMA (W1 two slices ahead, W2 one ahead), one workgroup barrier per
+// slice, which also orders the accumulator exchange.  Arithmetic: fp16 hi + lo split operands, three products,
+// fp32 accumulation (exact mode); bf16, one product (fast mode).  Weights are pre-scaled by 2^wshift.
+#include "common.h"
+#include "planes.h"
+
+struct FfnArgs {
+    const float* x;               // [M, 128] source; also the residual
+    const float* y;               // [M, 128] message
+    const unsigned short* w1;     // [NS][hid][256], pre-scaled by 2^wshift
+    long w1_plane_stride;
+    const unsigned short* w2;     // [NS][128][hid], pre-scaled by 2^wshift
+    long w2_plane_stride;
+    const float* gamma;
+    const float* beta;
+    float* out;                   // [M, 128]
+    int M, hid;
+    float out_scale;              // 2^-wshift
+    float eps;
+};
+
+__device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ float ffn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int NS>
+struct FfnLds {
+    static constexpr int W1P = 32 * 512;         // one plane of a W1 slice: 32 hidden rows x 256 k x 2 B
+    static constexpr int W1S = NS * W1P;
+    static constexpr int W2P = 128 * 64;         // one plane of a W2 slice: 128 output rows x 32 hidden x 2 B
+    static constexpr int W2S = NS * W2P;
+    static constexpr int W1_OFF = 0, W2_OFF = 2 * W1S, XB_OFF = W2_OFF + 2 * W2S;
+    static constexpr int XB = 2048;              // one wave's outgoing accumulator half
+    static constexpr int RING = XB_OFF + 2 * 8 * XB;
+    static constexpr int TOTAL = RING > 65536 ? RING : 65536;    // the epilogue overlays 4 x 16 KB of partial O
+};
+
+template <typename T, int NS>
+__global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
+    using L = FfnLds<NS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, role = wave >> 2;                 // partners w, w ^ 4 sit on the same SIMD
+    const int half = lane >> 5, tl = lane & 31;
+    const int m0 = blockIdx.x * 128;
+    const int tok = m0 + 32 * pair + tl;
+    const int nslice = a.hid >> 5;
+
+    // ---- weight slices by LDS-DMA; the XOR swizzles are applied on the source side ---------------------------------
+    // W1 slice: 16-byte chunk c (of 32) of row r sits at chunk c ^ r; one instruction moves two rows.
+    auto dma_w1 = [&](int j, int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 8 * i + wave;
+            const int r = 2 * blk + half, c = tl ^ r;
+            const unsigned off = (unsigned)((((long)(32 * j + r)) * 256 + 8 * c) * 2);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                ffn_dma16(a.w1 + pl * a.w1_plane_stride, off, lds + L::W1_OFF + slot * L::W1S + pl * L::W1P + blk * 1024);
+        }
+    };
+    // W2 slice: rows of 64 B (4 chunks), chunk c of row r at c ^ ((r >> 2) & 3); one instruction moves 16 rows.
+    auto dma_w2 = [&](int j, int slot) {
+        const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+        const unsigned off = (unsigned)((((long)r) * a.hid + 32 * j + 8 * c) * 2);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+            ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
+    };
+
+    dma_w1(0, 0);
+
+    // ---- token operand: this role's 128 of the 256 input features, as B fragments (k = 16 ks + 8 half + 0..7) ----
+    i16x8 xf[NS][8];
+    {
+        const float* src = (role ? a.y : a.x) + (long)min(tok, a.M - 1) * 128 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
+            xf[0][ks] = __builtin_bit_cast(i16x8, h);
+            if (NS == 2) {
+                const f32x2 u0 = T::unpack2(h[0]), u1 = T::unpack2(h[1]), u2 = T::unpack2(h[2]), u3 = T::unpack2(h[3]);
+                const u32x4 l = {T::pack2(v0[0] - u0[0], v0[1] - u0[1]), T::pack2(v0[2] - u1[0], v0[3] - u1[1]),
+                                 T::pack2(v1[0] - u2[0], v1[1] - u2[1]), T::pack2(v1[2] - u3[0], v1[3] - u3[1])};
+                xf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
+            }
+        }
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ot][r] = 0.f;
+
+    // fragment offsets.  Phase A: W1 row (tl ^ 16 role), chunk 16 role + 2 ks + half.  Phase B: W2 row 32 ot + tl,
+    // chunk 2 role + half.
+    const int arow = tl ^ (16 * role);
+    int aoff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) aoff[ks] = arow * 512 + (((16 * role + 2 * ks + half) ^ arow) << 4);
+    int boff[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        const int r = 32 * ot + tl;
+        boff[ot] = r * 64 + (((2 * role + half) ^ ((r >> 2) & 3)) << 4);
+    }
+    unsigned char* xb_out = lds + L::XB_OFF + wave * L::XB + lane * 16;
+    const unsigned char* xb_in = lds + L::XB_OFF + (wave ^ 4) * L::XB + lane * 16;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nslice > 1) dma_w1(1, 1);
+    dma_w2(0, 0);
+
+    for (int j = 0; j < nslice; ++j) {
+        const int slot = j & 1;
+        const unsigned char* w1s = lds + L::W1_OFF + slot * L::W1S;
+        const unsigned char* w2s = lds + L::W2_OFF + slot * L::W2S;
+
+        // ---- phase A: partial S^T over this role's half of K ------------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        {
+            i16x8 fh[3], fl[3];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
+                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
+                }
+                if (NS == 2) {
+                    sc = T::mfma(fl[ks % 3], xf[0][ks], sc);
+                    sc = T::mfma(fh[ks % 3], xf[NS - 1][ks], sc);
+                }
+                sc = T::mfma(fh[ks % 3], xf[0][ks], sc);
+            }
+            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        // ---- exchange: rows 16..31 of the accumulator go to the partner ---------------------------------------------
+        {
+            unsigned char* p = xb_out + slot * (8 * L::XB);
+            *reinterpret_cast<f32x4*>(p) = f32x4{sc[8], sc[9], sc[10], sc[11]};
+            *reinterpret_cast<f32x4*>(p + 1024) = f32x4{sc[12], sc[13], sc[14], sc[15]};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(j+1), W2(j): this thread's pieces have landed
+        __syncthreads();
+        if (j + 2 < nslice) dma_w1(j + 2, slot);
+        if (j + 1 < nslice) dma_w2(j + 1, slot ^ 1);
+        float hv[8];
+        {
+            const unsigned char* p = xb_in + slot * (8 * L::XB);
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(p + 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hv[i] = ffn_gelu((sc[i] + r0[i]) * a.out_scale);
+                hv[4 + i] = ffn_gelu((sc[4 + i] + r1[i]) * a.out_scale);
+            }
+        }
+
+        // ---- H^T operand fragments for the wave's 16 hidden units (one k-step) ---------------------------------------
+        i16x8 pf[NS];
+        {
+            unsigned wh[4], wl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wh[q] = T::pack2(hv[2 * q], hv[2 * q + 1]);
+                if (NS == 2) {
+                    const f32x2 u = T::unpack2(wh[q]);
+                    wl[q] = T::pack2(hv[2 * q] - u[0], hv[2 * q + 1] - u[1]);
+                }
+            }
+            {
+                const auto sx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
+                const u32x4 f = {sx[0], sy[0], sx[1], sy[1]};
+                pf[0] = __builtin_bit_cast(i16x8, f);
+            }
+            if (NS == 2) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
+                const u32x4 f = {sx[0], sy[0], sx[1], sy[1]};
+                pf[NS - 1] = __builtin_bit_cast(i16x8, f);
+            }
+        }
+
+        // ---- phase B: O^T += W2[:, own 16 hidden] . H^T -----------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const i16x8 vh = *reinterpret_cast<const i16x8*>(w2s + boff[ot]);
+            if (NS == 2) {
+                const i16x8 vl = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
+                o[ot] = T::mfma(vl, pf[0], o[ot]);
+                o[ot] = T::mfma(vh, pf[NS - 1], o[ot]);
+            }
+            o[ot] = T::mfma(vh, pf[0], o[ot]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue: add the partner's partial O, LayerNorm over the 128 outputs, residual ------------------------------
+    __syncthreads();                                               // every ring slot and exchange buffer is dead
+    unsigned char* ob = lds + pair * 16384 + lane * 16;
+    if (role == 1) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(ob + (4 * ot + g) * 1024) =
+                    f32x4{o[ot][4 * g], o[ot][4 * g + 1], o[ot][4 * g + 2], o[ot][4 * g + 3]};
+    }
+    __syncthreads();
+    if (role == 1) return;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(ob + (4 * ot + g) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = (o[ot][4 * g + i] + r[i]) * a.out_scale;
+        }
+    float s1 = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += o[ot][r];
+    float u, v2;
+    half_wave_pair(s1, u, v2);
+    const float mean = (u + v2) * (1.0f / 128.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = o[ot][r] - mean;
+            s2 = __builtin_fmaf(d, d, s2);
+        }
+    half_wave_pair(s2, u, v2);
+    const float rstd = 1.0f / sqrtf((u + v2) * (1.0f / 128.0f) + a.eps);
+    if (tok < a.M) {
+        // lane holds, for its token, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot)
+        float* dst = a.out + (long)tok * 128 + 4 * half;
+        const float* res = a.x + (long)tok * 128 + 4 * half;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * ot + 8 * g;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + n + 4 * half);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + n + 4 * half);
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(res + n);
+                f32x4 yv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yv[i] = (o[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i] + rr[i];
+                *reinterpret_cast<f32x4*>(dst + n) = yv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+extern void um_set_error(const char* fmt, ...);
+
+template <typename T, int NS>
+static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
+    static bool configured = false;          // opt in to > 64 KB of LDS once per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_kernel<T, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FfnLds<NS>::TOTAL);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    ScopedKernelTimer timer(UM_K_FFN, stream);
+    hipLaunchKernelGGL((ffn_kernel<T, NS>), dim3((a.M + 127) / 128), dim3(512), FfnLds<NS>::TOTAL, stream, a);
+    return hipGetLastError();
+}
+
+extern "C" int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                          int wshift, const float* gamma, const float* beta, float eps, float* out, int mode,
+                          void* stream_) {
+    if (!x || !y || !w1_planes || !w2_planes || !gamma || !beta || !out || m <= 0 || hidden < 64 || hidden % 32 != 0 ||
+        (mode != 0 && mode != 1) || wshift < 0 || wshift > 14) {
+        um_set_error("um_ffn_fwd: bad argument (m=%d hidden=%d wshift=%d mode=%d; hidden must be a multiple of 32, >= 64)",
+                     m, hidden, wshift, mode);
+        return -1;
+    }
+    if ((long)hidden * 256 * 2 >= (1L << 32)) {
+        um_set_error("um_ffn_fwd: weight planes beyond 4 GiB are not addressable by this kernel");
+        return -4;
+    }
+    FfnArgs a;
+    a.x = x;
+    a.y = y;
+    a.w1 = (const unsigned short*)w1_planes;
+    a.w1_plane_stride = (long)hidden * 256;
+    a.w2 = (const unsigned short*)w2_planes;
+    a.w2_plane_stride = (long)128 * hidden;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.out = out;
+    a.M = m;
+    a.hid = hidden;
+    a.out_scale = ldexpf(1.f, -wshift);
+    a.eps = eps;
+    const hipError_t e = mode == 0 ? launch_ffn<Fp16, 2>(a, (hipStream_t)stream_) : launch_ffn<Bf16, 1>(a, (hipStream_t)stream_);
+    if (e != hipSuccess) {
+        um_set_error("um_ffn_fwd: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}

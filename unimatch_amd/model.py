@@ -117,7 +117,7 @@ class TransformerLayer(nn.Module):
 
     def _forward_fused(self, ops, source, target, h, w, geom):
         """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
-        (+ residual) is one kernel, the FFN is two kernels with no concatenated / fp32 hidden tensor."""
+        (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``)."""
         s, l, c = source.shape
         m = s * l
         src = source.reshape(m, c)
@@ -132,6 +132,8 @@ class TransformerLayer(nn.Module):
         if self.no_ffn:
             return ops.linear_ln(att, (self.merge.weight,), self.norm1, residual=src).reshape(s, l, c)
         msg = ops.linear_ln(att, (self.merge.weight,), self.norm1)
+        if getattr(ops, 'fused_ffn', False):      # one kernel, the [M, 8C] hidden activations never reach HBM
+            return ops.ffn_ln(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2).reshape(s, l, c)
         hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)
         return ops.linear_ln(hid, (self.mlp[2].weight,), self.norm2, residual=src, a_planes_k=nh).reshape(s, l, c)
 

@@ -55,6 +55,7 @@ class HipOps:
     """The hot path on MI355X.  ``precision``: 'exact' (fp16 hi+lo split MFMA operands) or 'fast' (bf16)."""
 
     fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
+    fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
     WSHIFT = 10                # weights are scaled by 2^10 before the fp16 split (exact), see linear.hip
 
     def __init__(self, precision='exact'):
@@ -163,6 +164,25 @@ class HipOps:
             _ptr(norm.weight), _ptr(norm.bias), _ptr(residual) if residual is not None else None,
             float(norm.eps), self.mode, _stream()), {'flops': 2.0 * m * n * k})
         _abi.check(code, 'um_linear_fwd')
+        return out
+
+    def ffn_ln(self, x, y, w1, w2, norm):
+        """``x + LayerNorm(W2 . gelu(W1 . [x | y]))`` in one kernel (``um_ffn_fwd``); x, y fp32 ``[M, 128]``,
+        ``w1`` ``[hidden, 256]``, ``w2`` ``[128, hidden]``, ``norm`` an ``nn.LayerNorm`` over 128."""
+        w1p, hid, k1 = self.weight_planes((w1,))
+        w2p, n2, k2 = self.weight_planes((w2,))
+        if (k1, n2, k2) != (256, 128, hid):
+            raise ValueError(f'ffn_ln: expected W1 [hidden, 256] and W2 [128, hidden], got {tuple(w1.shape)} {tuple(w2.shape)}')
+        self._check_rows('x', x, 128)
+        self._check_rows('y', y, 128)
+        m = x.shape[0]
+        if y.shape[0] != m:
+            raise ValueError('ffn_ln: x and y must have the same number of rows')
+        out = torch.empty((m, 128), dtype=torch.float32, device=x.device)
+        code = self._launch('ffn', lambda: self.lib.um_ffn_fwd(
+            _ptr(x), _ptr(y), _ptr(w1p), _ptr(w2p), m, hid, self.WSHIFT, _ptr(norm.weight), _ptr(norm.bias),
+            float(norm.eps), _ptr(out), self.mode, _stream()), {'flops': 2.0 * m * hid * (256 + 128)})
+        _abi.check(code, 'um_ffn_fwd')
         return out
 
     def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0):
