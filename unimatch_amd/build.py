@@ -13,6 +13,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libunimatch_hip.so')
 SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'norm_ops.hip', 'upsample.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
+# per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
+EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 
@@ -41,7 +43,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True, cwd=CSRC)

@@ -23,6 +23,7 @@
 // Weight slices stream through LDS by LDS-DMA (W1 two slices ahead, W2 one ahead), one workgroup barrier per
 // slice, which also orders the accumulator exchange.  Arithmetic: fp16 hi + lo split operands, three products,
 // fp32 accumulation (exact mode); bf16, one product (fast mode).  Weights are pre-scaled by 2^wshift.
+#include <type_traits>
 #include "common.h"
 #include "planes.h"
 
@@ -51,7 +52,70 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
                  : "memory");
 }
 
-__device__ __forceinline__ float ffn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+#ifndef UM_FFN_ABL
+#define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
+#endif
+// erf-GELU on two values at once, branch free (ocml's erff is two divergent branches per element: ~40 VALU slots and a
+// scheduling wall between every element).  erf: the two minimax pieces of N. Juffa's single-precision erff
+// (|a| > 0.927734375: 1 - exp(p(t)); else a + a q(a^2)), both evaluated, packed fp32 FMAs; 1.2 ulp measured against
+// fp64 over [-6, 6] (v_exp_f32 argument rounding included), i.e. gelu error < 0.6 ulp of x.
+struct Gelu2 {
+    float x[2], a[2], t[2], s[2], r[2], q[2];      // after stage 7: x holds gelu(x)
+};
+// One of eight stages of ~4 instructions per value (the main loop pins stages behind MFMAs).  Scalar fp32 on purpose:
+// packed fp32 VALU issues slower beside MFMAs than the two scalar instructions it replaces (MI355X_MICROARCH.md).
+__device__ __forceinline__ void ffn_gelu_stage(Gelu2& g, int stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (UM_FFN_ABL & 1) {
+            if (stage == 7) g.x[i] = g.x[i] * 0.5f;
+            continue;
+        }
+        switch (stage) {
+        case 0:
+            g.a[i] = g.x[i] * 0.70710678118654752f;
+            g.t[i] = __builtin_fabsf(g.a[i]);
+            g.s[i] = g.a[i] * g.a[i];
+            break;
+        case 1: {
+            g.r[i] = __builtin_fmaf(-1.72853470e-5f, g.t[i], 3.83197126e-4f);
+            const float u = __builtin_fmaf(-3.88396438e-3f, g.t[i], 2.42546219e-2f);
+            g.r[i] = __builtin_fmaf(g.r[i], g.s[i], u);
+            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -1.06777877e-1f);
+            break;
+        }
+        case 2:
+            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -6.34846687e-1f);
+            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -1.28717512e-1f);
+            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -g.t[i]);
+            g.r[i] = g.r[i] * UM_LOG2E;
+            break;
+        case 3:
+            g.r[i] = fast_exp2(g.r[i]);
+            g.q[i] = __builtin_fmaf(-5.96761703e-4f, g.s[i], 4.99119423e-3f);
+            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], -2.67681349e-2f);
+            break;
+        case 4:
+            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], 1.12819925e-1f);
+            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], -3.76125336e-1f);
+            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], 1.28379166e-1f);
+            break;
+        case 5:
+            g.q[i] = __builtin_fmaf(g.q[i], g.a[i], g.a[i]);
+            g.r[i] = 1.0f - g.r[i];
+            break;
+        case 6:
+            g.r[i] = __builtin_copysignf(g.r[i], g.a[i]);
+            g.q[i] = g.t[i] > 0.927734375f ? g.r[i] : g.q[i];
+            break;
+        default: {
+            const float hx = g.x[i] * 0.5f;
+            g.x[i] = __builtin_fmaf(hx, g.q[i], hx);
+            break;
+        }
+        }
+    }
+}
 
 template <int NS>
 struct FfnLds {
@@ -142,112 +206,235 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     unsigned char* xb_out = lds + L::XB_OFF + wave * L::XB + lane * 16;
     const unsigned char* xb_in = lds + L::XB_OFF + (wave ^ 4) * L::XB + lane * 16;
 
+    // ---- phase A of one slice: partial S^T over this role's half of K (no scheduling directives: the caller owns the
+    // scheduling region, because this runs interleaved with the GELU of the previous slice)
+    auto phase_a = [&](const unsigned char* w1s, f32x16& sc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        if (UM_FFN_ABL & 4) return;
+        i16x8 fh[3], fl[3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
+            if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 2 < 8) {
+                fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
+                if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
+            }
+            if (NS == 2) {
+                sc = T::mfma(fl[ks % 3], xf[0][ks], sc);
+                sc = T::mfma(fh[ks % 3], xf[NS - 1][ks], sc);
+            }
+            sc = T::mfma(fh[ks % 3], xf[0][ks], sc);
+        }
+    };
+    // rows 16..31 of the accumulator go to the partner
+    auto send = [&](const f32x16& sc, int parity) {
+        if (UM_FFN_ABL & 16) return;
+        unsigned char* p = xb_out + parity * (8 * L::XB);
+        *reinterpret_cast<f32x4*>(p) = f32x4{sc[8], sc[9], sc[10], sc[11]};
+        *reinterpret_cast<f32x4*>(p + 1024) = f32x4{sc[12], sc[13], sc[14], sc[15]};
+    };
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (nslice > 1) dma_w1(1, 1);
-    dma_w2(0, 0);
 
-    for (int j = 0; j < nslice; ++j) {
-        const int slot = j & 1;
-        const unsigned char* w1s = lds + L::W1_OFF + slot * L::W1S;
-        const unsigned char* w2s = lds + L::W2_OFF + slot * L::W2S;
-
-        // ---- phase A: partial S^T over this role's half of K ------------------------------------------------------
-        f32x16 sc;
+    f32x16 sc;                      // rows 0..15 (regs 0..7): the wave's own hidden units of the current slice
+    __builtin_amdgcn_s_setprio(1);
+    phase_a(lds + L::W1_OFF, sc);
+    {
+        constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-        {
-            i16x8 fh[3], fl[3];
-            __builtin_amdgcn_s_setprio(1);
+        for (int ks = 0; ks < 6; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    send(sc, 0);
+
+    // H^T operand fragments of the wave's 16 hidden units (one k-step), built in four stages from the GELU outputs
+    struct Frag {
+        unsigned wh[4], wl[4];
+        f32x2 u[4];
+    };
+    auto frag_stage = [&](Frag& f, const Gelu2* g, i16x8* pf, int stage) {
+        switch (stage) {
+        case 0:
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f.wh[q] = T::pack2(g[q].x[0], g[q].x[1]);
+            break;
+        case 1:
+            if (NS == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.u[q] = T::unpack2(f.wh[q]);
+            }
+            break;
+        case 2:
+            if (NS == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.wl[q] = T::pack2(g[q].x[0] - f.u[q][0], g[q].x[1] - f.u[q][1]);
+            }
+            break;
+        default: {
+            const auto sx = __builtin_amdgcn_permlane32_swap(f.wh[0], f.wh[2], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(f.wh[1], f.wh[3], false, false);
+            const u32x4 fh = {sx[0], sy[0], sx[1], sy[1]};
+            pf[0] = __builtin_bit_cast(i16x8, fh);
+            if (NS == 2) {
+                const auto tx = __builtin_amdgcn_permlane32_swap(f.wl[0], f.wl[2], false, false);
+                const auto ty = __builtin_amdgcn_permlane32_swap(f.wl[1], f.wl[3], false, false);
+                const u32x4 fl = {tx[0], ty[0], tx[1], ty[1]};
+                pf[NS - 1] = __builtin_bit_cast(i16x8, fl);
+            }
+            break;
+        }
+        }
+    };
+
+    // One iteration i (after barrier i):
+    //     MFMA pipe :  phase B of slice i-1 (12 MFMAs, fragments built last iteration)  then  phase A of slice i+1 (24)
+    //     VALU      :  GELU of slice i (32 stages) and its H^T fragments (4 stages), pinned behind those MFMAs
+    // hipcc does not interleave the two on its own (and gives up on a sched_group_barrier pipeline of this size), so the
+    // order is written out: every MFMA is followed by its share of stages and a scheduling fence.
+    i16x8 pf[NS];                   // H^T fragments of the previous slice
+    auto iteration = [&](auto has_a_tag, auto has_b_tag, int i) {
+        constexpr bool HAS_A = decltype(has_a_tag)::value && !(UM_FFN_ABL & 4);
+        constexpr bool HAS_B = decltype(has_b_tag)::value && !(UM_FFN_ABL & 8);
+        constexpr int MF = (NS == 2) ? 3 : 1;
+        constexpr int NMFMA = (HAS_A ? 8 * MF : 0) + (HAS_B ? 4 * MF : 0);
+        constexpr int NSTAGE = 36;
+        const int slot = i & 1;
+        const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
+        const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(i+1), W2(i-1): this thread's pieces have landed
+        __syncthreads();
+        if (!(UM_FFN_ABL & 2)) {
+            if (i + 2 < nslice) dma_w1(i + 2, slot);
+            dma_w2(i, slot);
+        }
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if (!(UM_FFN_ABL & 16)) {
+            const unsigned char* p = xb_in + slot * (8 * L::XB);
+            r0 = *reinterpret_cast<const f32x4*>(p);
+            r1 = *reinterpret_cast<const f32x4*>(p + 1024);
+        }
+        Gelu2 g[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                g[q].x[i] = (sc[2 * q + i] + r0[2 * q + i]) * a.out_scale;
+                g[2 + q].x[i] = (sc[4 + 2 * q + i] + r1[2 * q + i]) * a.out_scale;
+            }
+        }
+        Frag fr;
+        i16x8 pfn[NS];
+        int done = 0;                                              // VALU stages issued so far (compile-time after unrolling)
+        auto valu_share = [&](int slot_idx) {                      // stages [slot_idx, slot_idx + 1) * NSTAGE / NMFMA
+            const int upto = (slot_idx + 1) * NSTAGE / (NMFMA > 0 ? NMFMA : 1);
+            for (; done < upto; ++done) {
+                if (done < 32) ffn_gelu_stage(g[done >> 3], done & 7);
+                else frag_stage(fr, g, pfn, done - 32);
+            }
+        };
+        f32x16 scn, scm;                                           // phase A alternates two accumulators (see phase B)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scn[r] = scm[r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+        int mslot = 0;
+        i16x8 fh[3], fl[3];                                        // phase A fragments, two k-steps ahead of their MFMAs
+        if (HAS_A) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
                 if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
             }
+        }
+        if (HAS_B) {
+            // product index outer, output tile inner: consecutive MFMAs write different accumulators (a filler between two
+            // MFMAs on the same accumulator costs the forwarding path, ~43 cycles -- MI355X_MICROARCH.md)
+            i16x8 vh[4], vl[4];
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                vh[ot] = *reinterpret_cast<const i16x8*>(w2s + boff[ot]);
+                if (NS == 2) vl[ot] = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
+            }
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    const i16x8 wa = (NS == 2 && m == 0) ? vl[ot] : vh[ot];
+                    const i16x8 hb = (NS == 2 && m == 1) ? pf[NS - 1] : pf[0];
+                    o[ot] = T::mfma(wa, hb, o[ot]);
+                    valu_share(mslot++);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 16, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if (HAS_A) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 2 < 8) {
                     fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
                     if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
                 }
-                if (NS == 2) {
-                    sc = T::mfma(fl[ks % 3], xf[0][ks], sc);
-                    sc = T::mfma(fh[ks % 3], xf[NS - 1][ks], sc);
-                }
-                sc = T::mfma(fh[ks % 3], xf[0][ks], sc);
-            }
-            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-
-        // ---- exchange: rows 16..31 of the accumulator go to the partner ---------------------------------------------
-        {
-            unsigned char* p = xb_out + slot * (8 * L::XB);
-            *reinterpret_cast<f32x4*>(p) = f32x4{sc[8], sc[9], sc[10], sc[11]};
-            *reinterpret_cast<f32x4*>(p + 1024) = f32x4{sc[12], sc[13], sc[14], sc[15]};
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(j+1), W2(j): this thread's pieces have landed
-        __syncthreads();
-        if (j + 2 < nslice) dma_w1(j + 2, slot);
-        if (j + 1 < nslice) dma_w2(j + 1, slot ^ 1);
-        float hv[8];
-        {
-            const unsigned char* p = xb_in + slot * (8 * L::XB);
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(p);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(p + 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hv[i] = ffn_gelu((sc[i] + r0[i]) * a.out_scale);
-                hv[4 + i] = ffn_gelu((sc[4 + i] + r1[i]) * a.out_scale);
-            }
-        }
-
-        // ---- H^T operand fragments for the wave's 16 hidden units (one k-step) ---------------------------------------
-        i16x8 pf[NS];
-        {
-            unsigned wh[4], wl[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wh[q] = T::pack2(hv[2 * q], hv[2 * q + 1]);
-                if (NS == 2) {
-                    const f32x2 u = T::unpack2(wh[q]);
-                    wl[q] = T::pack2(hv[2 * q] - u[0], hv[2 * q + 1] - u[1]);
+                for (int m = 0; m < MF; ++m) {
+                    const i16x8 wa = (NS == 2 && m == 0) ? fl[ks % 3] : fh[ks % 3];
+                    const i16x8 xb = (NS == 2 && m == 1) ? xf[NS - 1][ks] : xf[0][ks];
+                    if ((ks * MF + m) & 1) scm = T::mfma(wa, xb, scm);
+                    else scn = T::mfma(wa, xb, scn);
+                    valu_share(mslot++);
+                    if (m == 0 && ks + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NS, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 16, 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            {
-                const auto sx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
-                const u32x4 f = {sx[0], sy[0], sx[1], sy[1]};
-                pf[0] = __builtin_bit_cast(i16x8, f);
-            }
-            if (NS == 2) {
-                const auto sx = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
-                const u32x4 f = {sx[0], sy[0], sx[1], sy[1]};
-                pf[NS - 1] = __builtin_bit_cast(i16x8, f);
-            }
-        }
-
-        // ---- phase B: O^T += W2[:, own 16 hidden] . H^T -----------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            const i16x8 vh = *reinterpret_cast<const i16x8*>(w2s + boff[ot]);
-            if (NS == 2) {
-                const i16x8 vl = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
-                o[ot] = T::mfma(vl, pf[0], o[ot]);
-                o[ot] = T::mfma(vh, pf[NS - 1], o[ot]);
-            }
-            o[ot] = T::mfma(vh, pf[0], o[ot]);
         }
         __builtin_amdgcn_s_setprio(0);
+        for (; done < NSTAGE; ++done) {                            // whatever no MFMA was left to hide
+            if (done < 32) ffn_gelu_stage(g[done >> 3], done & 7);
+            else frag_stage(fr, g, pfn, done - 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(has_a_tag)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scn[r] += scm[r];
+            send(scn, slot ^ 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sc[r] = scn[r];
+        }
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) pf[pl] = pfn[pl];
+    };
+    iteration(std::true_type{}, std::false_type{}, 0);
+    for (int i = 1; i + 1 < nslice; ++i) iteration(std::true_type{}, std::true_type{}, i);
+    iteration(std::false_type{}, std::true_type{}, nslice - 1);
+    {   // phase B of the last slice
+        const unsigned char* w2s = lds + L::W2_OFF + ((nslice - 1) & 1) * L::W2S;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!(UM_FFN_ABL & 8)) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                const i16x8 vh = *reinterpret_cast<const i16x8*>(w2s + boff[ot]);
+                if (NS == 2) {
+                    const i16x8 vl = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
+                    o[ot] = T::mfma(vl, pf[0], o[ot]);
+                    o[ot] = T::mfma(vh, pf[NS - 1], o[ot]);
+                }
+                o[ot] = T::mfma(vh, pf[0], o[ot]);
+            }
+        }
     }
 
     // ---- epilogue: add the partner's partial O, LayerNorm over the 128 outputs, residual ------------------------------
