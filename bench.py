@@ -47,7 +47,7 @@ def parse():
     return ap.parse_args()
 
 
-UM_K_COUNT = 11      # include/unimatch_hip.h
+UM_K_COUNT = 12      # include/unimatch_hip.h
 
 
 def collect(lib, kid):

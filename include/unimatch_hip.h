@@ -61,7 +61,8 @@ const char* um_last_error_string(void);
 #define UM_K_INSTANCE_NORM 8 /* instance_norm_kernel (um_instance_norm_fwd)                              */
 #define UM_K_CONVEX_UPSAMPLE 9 /* convex_upsample_kernel (um_convex_upsample)                            */
 #define UM_K_FFN 10          /* ffn_kernel (um_ffn_fwd)                                                  */
-#define UM_K_COUNT 11
+#define UM_K_CONV 11         /* conv_kernel (um_conv2d_fwd)                                              */
+#define UM_K_COUNT 12
 int um_timing_enable(int on);
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
@@ -123,6 +124,34 @@ int um_linear_fwd(const float* a0, const float* a1, const void* a_planes, const 
  * through HBM).  hidden: multiple of 32, >= 64.  out: fp32 [M,128], may not alias x or y. */
 int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
                int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolutions either side of the matching path, NHWC, on the matrix cores with the same
+ * operand arithmetic as everything else (`mode`): nn.Conv2d of unimatch/reg_refine.py:6-119 (3x3, 1x1, 1x5, 5x1, 7x7)
+ * and unimatch/backbone.py:7-133 (3x3 at stride 1/2, 1x1 projections), dilation 1, groups 1.
+ *   a_planes : activations as operand planes [NS][batch*hi*wi + 1][cin], NHWC, whose LAST row is all zeros (taps outside
+ *              the image read it).  Written by um_nhwc_instance_norm / um_nchw_to_nhwc.  cin: multiple of 32.
+ *   w_planes : um_weight_planes() of the weight permuted to [cout][kh][kw][cin] (n = cout, k = kh*kw*cin), same wshift.
+ *   out      : fp32 [batch*ho*wo][cout] (NHWC), ho = (hi + 2 pad_h - kh) / stride + 1; + bias[cout] if not NULL; ReLU if relu.
+ * ------------------------------------------------------------------------------------------- */
+int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, int batch, int hi, int wi,
+                  int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int wshift, int mode,
+                  void* stream);
+
+/* nn.InstanceNorm2d (affine=False, biased variance) + ReLU (+ shortcut add + ReLU) of unimatch/backbone.py:7-36 in NHWC:
+ *   y = x (normalize == 0) | (x - mean_{b,c}) * rsqrt(var_{b,c} + eps);  y = relu(y) if relu;  y = relu(shortcut + y) if
+ * shortcut.  x, shortcut: fp32 [batch*pixels][channels].  Outputs (either may be NULL): operand planes
+ * [NS][batch*pixels + 1][channels] including the zero row um_conv2d_fwd expects, and fp32 [batch*pixels][channels].
+ * Statistics are deterministic (fixed reduction order, chunk-shifted sums merged in fp64).  channels: multiple of 8, <= 256. */
+size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channels);
+int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch, int pixels,
+                          int channels, float eps, int normalize, int relu, void* workspace, size_t workspace_bytes,
+                          int mode, void* stream);
+
+/* fp32 NCHW [batch][channels][pixels] (the output of a MIOpen convolution) -> NHWC operand planes (with the zero row)
+ * and / or fp32 NHWC.  channels: multiple of 8, <= 256. */
+int um_nchw_to_nhwc(const float* x, void* planes_out, float* f32_out, int batch, int channels, int pixels, int mode,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs correlation + softmax + expected coordinate (flow).

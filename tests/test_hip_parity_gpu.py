@@ -382,6 +382,66 @@ def test_fused_ffn_rejects_bad_arguments(ops):
         ops.ffn_ln(x, x, rnd(87, 48, 256).to(DEV), rnd(88, 128, 48).to(DEV), norm)         # hidden % 32 != 0
 
 
+# ------------------------------------------------------------------ NHWC convolutions + encoder glue
+def _nhwc_planes(ops, x_nchw):
+    """NCHW fp32 (CPU) -> the library's NHWC operand planes via um_nchw_to_nhwc."""
+    planes, f32 = ops.nchw_to_nhwc(x_nchw.to(DEV).contiguous(), want_planes=True, want_f32=True)
+    return planes, f32
+
+
+@pytest.mark.parametrize('case', [
+    # b, cin, cout, h, w, kh, kw, stride, ph, pw, bias, relu
+    (2, 64, 64, 20, 28, 3, 3, 1, 1, 1, False, False),        # encoder layer1
+    (1, 64, 96, 21, 30, 3, 3, 2, 1, 1, False, False),        # stride 2, odd size
+    (2, 96, 96, 9, 13, 3, 3, 1, 1, 1, False, True),          # NT = 3 tile, fused ReLU
+    (1, 64, 96, 16, 24, 1, 1, 2, 0, 0, True, False),         # 1x1 projection shortcut with bias
+    (1, 128, 128, 8, 12, 3, 3, 1, 1, 1, False, False),       # NT = 4
+    (1, 128, 256, 7, 9, 3, 3, 1, 1, 1, True, True),          # two output tiles (flow head / mask head shape)
+    (1, 256, 128, 6, 10, 1, 5, 1, 0, 2, True, False),        # SepConvGRU horizontal
+    (1, 256, 128, 10, 6, 5, 1, 1, 2, 0, True, False),        # SepConvGRU vertical
+    (1, 32, 68, 5, 7, 7, 7, 1, 3, 3, True, False),           # 7x7, ragged cout
+])
+def test_conv2d_nhwc_matches_fp64(ops, case):
+    """um_conv2d_fwd (implicit GEMM on split-fp16 planes) against torch conv2d in fp64: every kernel geometry the
+    encoder and the refinement block use; zero padding comes from the planes' zero row."""
+    b, cin, cout, h, w, kh, kw, stride, ph, pw, bias, relu = case
+    x = rnd(90, b, cin, h, w, scale=1.5)
+    wt = rnd(91, cout, cin, kh, kw, scale=(2.0 / (cin * kh * kw)) ** 0.5)
+    bs = rnd(92, cout) if bias else None
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), bs.double() if bias else None, stride=stride, padding=(ph, pw))
+    if relu:
+        want = want.relu()
+    planes, _ = _nhwc_planes(ops, x)
+    got, ho, wo = ops.conv2d_nhwc((planes, b, h, w, cin), wt.to(DEV), bs.to(DEV) if bias else None, stride, (ph, pw), relu)
+    assert (ho, wo) == tuple(want.shape[-2:])
+    got = got.view(b, ho, wo, cout).permute(0, 3, 1, 2)
+    assert err(got, want)[0] < 3e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 37, 29), (1, 96, 64, 48), (3, 128, 5, 7)])
+def test_nhwc_instance_norm(ops, shape):
+    """NHWC InstanceNorm (+ ReLU, + shortcut + ReLU) against fp64, both output formats; a large mean exercises the
+    shifted statistics.  Planes are checked by summing hi + lo."""
+    b, c, h, w = shape
+    x = rnd(93, b, c, h, w, scale=2.0) + 30.0 * rnd(94, 1, c, 1, 1)
+    sc = rnd(95, b, c, h, w)
+    _, xf = ops.nchw_to_nhwc(x.to(DEV).contiguous(), want_planes=False, want_f32=True)
+    assert torch.equal(xf.view(b, h, w, c).permute(0, 3, 1, 2).cpu(), x)
+    _, scf = ops.nchw_to_nhwc(sc.to(DEV).contiguous(), want_planes=False, want_f32=True)
+    n64 = torch.nn.functional.instance_norm(x.double())
+    for relu, shortcut in ((True, None), (False, None), (True, scf)):
+        want = n64.relu() if relu else n64
+        if shortcut is not None:
+            want = (want + sc.double()).relu()
+        planes, f32 = ops.nhwc_norm(xf, b, h * w, relu=relu, shortcut=shortcut, want_planes=True, want_f32=True)
+        got = f32.view(b, h, w, c).permute(0, 3, 1, 2)
+        assert err(got, want)[0] < 2e-5
+        rows = b * h * w
+        pl = planes.view(torch.float16).view(2, rows + 1, c).float()
+        assert torch.equal(pl[:, rows], torch.zeros(2, c, device=DEV))              # the padding row
+        assert (pl[:, :rows].sum(0) - f32).abs().max().item() < 2e-6 * max(1.0, f32.abs().max().item())
+
+
 def test_fused_layer_matches_unfused_layer(ops, golden):
     """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
     g = golden('transformer')

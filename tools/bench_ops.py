@@ -15,7 +15,7 @@ from unimatch_amd import _abi  # noqa: E402
 from unimatch_amd.ops import HipOps  # noqa: E402
 
 KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr', 'linear',
-          'instance_norm', 'convex_upsample', 'ffn']
+          'instance_norm', 'convex_upsample', 'ffn', 'conv']
 PEAK = 2.5e15
 
 

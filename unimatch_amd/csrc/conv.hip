@@ -1,0 +1,275 @@
+// 2-D convolution as an implicit GEMM on the matrix cores, NHWC.                        gfx950 / wave64 / MFMA
+//
+//   out[p, co] = bias[co] + sum_{ky,kx,ci} in[b, y*s - ph + ky, x*s - pw + kx, ci] * W[co, ky, kx, ci]      p = (b, y, x)
+//
+// for the convolutions that sit either side of the matching path: the refinement block (SURVEY.md 8(f) rank 3:
+// unimatch/reg_refine.py:6-119 -- 3x3, 1x1, 1x5 / 5x1, 7x7) and the residual encoder (unimatch/backbone.py:7-133 -- 3x3
+// at stride 1 / 2, 1x1 projections).  MIOpen runs these in fp32 Winograd at 105-116 TFLOP/s effective; this kernel uses
+// the same "exact" arithmetic as the rest of the library (fp16 hi + lo split operands, three MFMA products, fp32
+// accumulation: fp32-equivalent results) and the same tile machinery as linear.hip.
+//
+// Operands: activations are ALREADY operand planes [NS][rows + 1][Cin] in NHWC order (written by the normalisation
+// kernel that precedes every convolution), with one extra all-zero row: a tap that falls outside the image reads that
+// row, so zero padding costs nothing in the main loop.  Weights are planes [NS][Cout][KH*KW*Cin] (tap-major, channel
+// minor), pre-scaled by 2^wshift.  The GEMM's K axis is walked tap by tap in chunks of 32 channels; for every chunk a
+// workgroup moves a [128 pixels x 32 channels] activation tile and a [32 NT outputs x 32] weight tile into a 2-slot
+// LDS ring by LDS-DMA -- the only per-tap work is two row indices per lane.
+// Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
+// computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
+#include "common.h"
+#include "planes.h"
+
+struct ConvArgs {
+    const unsigned short* ap;     // [NS][rows_in + 1][Cin], row rows_in = zeros
+    long a_plane_stride;
+    const unsigned short* wp;     // [NS][Cout][taps * Cin]
+    long w_plane_stride;
+    const float* bias;            // [Cout] or null
+    float* out;                   // [M][Cout]
+    int B, Hi, Wi, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad_h, pad_w;
+    int M;                        // B * Ho * Wo
+    int relu;
+    float out_scale;              // 2^-wshift
+};
+
+__device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(dst)
+                 : "memory");
+}
+
+template <typename T, int NS, int NT>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
+    constexpr int TILE = 128 * 64;               // one 128-row x 64-byte operand tile (one plane, one stage)
+    constexpr int STAGE = 2 * NS * TILE;         // activation planes then weight planes (sized for NT = 4)
+    constexpr int EPI = 4 * 32 * (32 * NT * 4);   // the epilogue's transposed tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * (32 * NT);
+    const int cpt = a.Cin >> 5;                  // 32-channel chunks per tap
+    const int nstage = a.KH * a.KW * cpt;
+    const int ktot = a.KH * a.KW * a.Cin;
+
+    // ---- the two pixels whose rows this lane moves (DMA: one instruction = 16 rows x 64 B; wave w moves rows 32w..) ----
+    const int dcp = lane & 3;
+    int py[2], px[2], pbase[2];                  // input-space origin (y*s - ph, x*s - pw) and image base row
+    bool pok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = m0 + 32 * wave + 16 * i + (lane >> 2);
+        pok[i] = p < a.M;
+        const int pp = pok[i] ? p : 0;
+        const int hw = a.Ho * a.Wo;
+        const int b = pp / hw, rem = pp - b * hw;
+        const int y = rem / a.Wo, x = rem - y * a.Wo;
+        py[i] = y * a.stride - a.pad_h;
+        px[i] = x * a.stride - a.pad_w;
+        pbase[i] = b * a.Hi * a.Wi;
+    }
+    const unsigned zero_row = (unsigned)a.B * a.Hi * a.Wi;
+    unsigned rowoff[2];                          // byte offset of the source row of the tap being staged
+    auto set_tap = [&](int ky, int kx) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = py[i] + ky, ix = px[i] + kx;
+            const bool ok = pok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const unsigned row = ok ? (unsigned)(pbase[i] + iy * a.Wi + ix) : zero_row;
+            rowoff[i] = row * (unsigned)(a.Cin * 2);
+        }
+    };
+    // 16-byte chunk cp of row r holds source chunk cp ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
+    auto stage_async = [&](int c0, int kglob, unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * wave + 16 * i + (lane >> 2);
+            const int sc = dcp ^ ((r >> 2) & 3);
+            const unsigned off = rowoff[i] + (unsigned)((c0 + 8 * sc) * 2);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * TILE + (32 * wave + 16 * i) * 64);
+        }
+        if (wave < NT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = 32 * wave + 16 * i + (lane >> 2);
+                const int sc = dcp ^ ((r >> 2) & 3);
+                const int n = min(n0 + r, a.Cout - 1);
+                const unsigned off = (unsigned)(((long)n * ktot + kglob + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * TILE + pl * TILE + (32 * wave + 16 * i) * 64);
+            }
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // fragment offsets inside a tile: row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4), chunk = 2 * kstep + half
+    const int fr = lane & 31;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = fr * 64 + (((2 * ks + half) ^ ((fr >> 2) & 3)) << 4);
+
+    // ---- prologue: stage 0 ------------------------------------------------------------------------------------
+    int ky = 0, kx = 0, cc = 0;                  // position of the NEXT stage to be issued
+    set_tap(0, 0);
+    stage_async(0, 0, lds);
+    auto advance = [&]() {                       // move (ky, kx, cc) one stage on; recompute the row offsets on a new tap
+        if (++cc == cpt) {
+            cc = 0;
+            if (++kx == a.KW) {
+                kx = 0;
+                ++ky;
+            }
+            set_tap(ky, kx);
+        }
+    };
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = 0; s < nstage; ++s) {
+        unsigned char* cur = lds + (s & 1) * STAGE;
+        unsigned char* nxt = lds + ((s & 1) ^ 1) * STAGE;
+        if (s + 1 < nstage) {
+            stage_async(cc * 32, (s + 1) * 32, nxt);
+            advance();
+        }
+        const unsigned char* at = cur + 32 * wave * 64;           // this wave's 32 pixel rows
+        const unsigned char* wt = cur + NS * TILE;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const i16x8 bh = *reinterpret_cast<const i16x8*>(at + foff[ks]);
+            i16x8 bl;
+            if (NS == 2) bl = *reinterpret_cast<const i16x8*>(at + TILE + foff[ks]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 64 + foff[ks]);
+                if (NS == 2) {
+                    const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + TILE + nt * 32 * 64 + foff[ks]);
+                    acc[nt] = T::mfma(wl, bh, acc[nt]);
+                    acc[nt] = T::mfma(wh, bl, acc[nt]);
+                }
+                acc[nt] = T::mfma(wh, bh, acc[nt]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, for pixel m0 + 32*wave + (lane & 31), outputs n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i) ----
+    // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
+    // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
+    constexpr int ROWB = 32 * NT * 4;                             // bytes per pixel row of the tile
+    unsigned char* stg = lds + wave * (32 * ROWB);
+    const int tl = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + 32 * nt + 8 * g + 4 * half;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[nt][4 * g + i] * a.out_scale;
+                if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
+                if (a.relu) v[i] = fmaxf(v[i], 0.f);
+            }
+            const int c = 8 * nt + 2 * g + half;                 // 16-byte chunk index inside the row
+            *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
+    constexpr int ITER = 32 * CPR / 64;
+    const int row0 = m0 + 32 * wave;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
+        if (row0 + r < a.M && n0 + 4 * c < a.Cout)
+            *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.Cout + n0 + 4 * c) = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+extern void um_set_error(const char* fmt, ...);
+
+template <int NT>
+static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
+    dim3 grid((a.M + 127) / 128, (a.Cout + 32 * NT - 1) / (32 * NT)), block(256);
+    ScopedKernelTimer timer(UM_K_CONV, stream);
+    if (mode == 0)
+        hipLaunchKernelGGL((conv_kernel<Fp16, 2, NT>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_kernel<Bf16, 1, NT>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, int batch, int hi,
+                             int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu,
+                             int wshift, int mode, void* stream_) {
+    if (!a_planes || !w_planes || !out || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 || cout <= 0 ||
+        cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) || wshift < 0 ||
+        wshift > 14) {
+        um_set_error("um_conv2d_fwd: bad argument (batch=%d hi=%d wi=%d cin=%d cout=%d k=%dx%d stride=%d pad=%d,%d; cin must be a "
+                     "multiple of 32, cout of 4)", batch, hi, wi, cin, cout, kh, kw, stride, pad_h, pad_w);
+        return -1;
+    }
+    const int ho = (hi + 2 * pad_h - kh) / stride + 1, wo = (wi + 2 * pad_w - kw) / stride + 1;
+    if (ho <= 0 || wo <= 0) {
+        um_set_error("um_conv2d_fwd: empty output (%d x %d)", ho, wo);
+        return -1;
+    }
+    const long rows_in = (long)batch * hi * wi, m = (long)batch * ho * wo;
+    if ((rows_in + 1) * cin * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
+        um_set_error("um_conv2d_fwd: operand planes beyond 4 GiB are not addressable by this kernel");
+        return -4;
+    }
+    ConvArgs a;
+    a.ap = (const unsigned short*)a_planes;
+    a.a_plane_stride = (rows_in + 1) * cin;
+    a.wp = (const unsigned short*)w_planes;
+    a.w_plane_stride = (long)cout * kh * kw * cin;
+    a.bias = bias;
+    a.out = out;
+    a.B = batch;
+    a.Hi = hi;
+    a.Wi = wi;
+    a.Cin = cin;
+    a.Ho = ho;
+    a.Wo = wo;
+    a.Cout = cout;
+    a.KH = kh;
+    a.KW = kw;
+    a.stride = stride;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
+    a.M = (int)m;
+    a.relu = relu;
+    a.out_scale = ldexpf(1.f, -wshift);
+    hipError_t e;
+    // widest output tile that does not waste more than a third of its columns
+    if (cout % 128 == 0 || cout > 192) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
+    else if (cout % 96 == 0) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
+    else if (cout <= 64 || cout % 64 == 0) e = launch_conv<2>(a, mode, (hipStream_t)stream_);
+    else e = launch_conv<4>(a, mode, (hipStream_t)stream_);
+    if (e != hipSuccess) {
+        um_set_error("um_conv2d_fwd: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}

@@ -230,6 +230,77 @@ class HipOps:
         _abi.check(code, 'um_instance_norm_fwd')
         return y
 
+    # ------------------------------------------------------------------ NHWC convolutions on the matrix cores
+    # (also what the encoder uses).  An "NHWC activation" here is a small record:
+    #   planes: operand planes [NS][rows + 1][C] (uint8 tensor; last row zero) or None
+    #   f32   : fp32 [rows, C] or None;   b, h, w, c: geometry, rows = b * h * w
+    def conv_weight_planes(self, weight):
+        """Planes of an ``nn.Conv2d`` weight ``[cout, cin, kh, kw]`` permuted to ``[cout, kh*kw*cin]``; cached."""
+        key = ('conv', weight.data_ptr(), weight._version, tuple(weight.shape))
+        hit = self._wcache.get(key)
+        if hit is not None:
+            return hit
+        cout, cin, kh, kw = weight.shape
+        w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous()
+        planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, self.mode), dtype=torch.uint8, device=w2.device)
+        _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, self.mode, _stream()),
+                   'um_weight_planes')
+        if len(self._wcache) > 256:
+            self._wcache.clear()
+        self._wcache[key] = (planes, cout, cin, kh, kw)
+        return self._wcache[key]
+
+    def conv2d_nhwc(self, act, weight, bias=None, stride=1, padding=(1, 1), relu=False):
+        """``act``: ``(planes, b, h, w, cin)``; returns fp32 ``[b*ho*wo, cout]`` and ``(ho, wo)``."""
+        planes, b, h, w, cin = act
+        wp, cout, wcin, kh, kw = self.conv_weight_planes(weight)
+        if wcin != cin:
+            raise ValueError(f'conv2d_nhwc: weight expects {wcin} input channels, activation has {cin}')
+        ph, pw = (padding, padding) if isinstance(padding, int) else padding
+        ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+        out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=planes.device)
+        meta = {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin}
+        code = self._launch('conv', lambda: self.lib.um_conv2d_fwd(
+            _ptr(planes), _ptr(wp), _ptr(bias) if bias is not None else None, _ptr(out), b, h, w, cin, cout, kh, kw,
+            stride, ph, pw, int(bool(relu)), self.WSHIFT, self.mode, _stream()), meta)
+        _abi.check(code, 'um_conv2d_fwd')
+        return out, ho, wo
+
+    def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5):
+        """InstanceNorm (+ ReLU, + shortcut + ReLU) of fp32 NHWC ``x [b*pixels, c]`` -> ``(planes | None, f32 | None)``."""
+        self._check_rows('x', x, x.shape[1])
+        c = x.shape[1]
+        if x.shape[0] != b * pixels:
+            raise ValueError('nhwc_norm: x must have b * pixels rows')
+        if shortcut is not None:
+            self._check_rows('shortcut', shortcut, c)
+        rows = b * pixels
+        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.mode), dtype=torch.uint8, device=x.device)
+                  if want_planes else None)
+        f32 = torch.empty_like(x) if want_f32 else None
+        ws = self._ws(self.lib.um_nhwc_norm_workspace_bytes(b, pixels, c), x.device) if normalize else None
+        code = self._launch('instance_norm', lambda: self.lib.um_nhwc_instance_norm(
+            _ptr(x), _ptr(shortcut) if shortcut is not None else None, _ptr(planes) if planes is not None else None,
+            _ptr(f32) if f32 is not None else None, b, pixels, c, float(eps), int(bool(normalize)), int(bool(relu)),
+            _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.mode, _stream()))
+        _abi.check(code, 'um_nhwc_instance_norm')
+        return planes, f32
+
+    def nchw_to_nhwc(self, x, want_planes=True, want_f32=False):
+        """fp32 NCHW map -> NHWC operand planes and / or fp32 ``[b*h*w, c]``."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+            raise ValueError('nchw_to_nhwc: expected a contiguous CUDA float32 NCHW tensor')
+        b, c, h, w = x.shape
+        rows = b * h * w
+        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.mode), dtype=torch.uint8, device=x.device)
+                  if want_planes else None)
+        f32 = torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
+        code = self._launch('instance_norm', lambda: self.lib.um_nchw_to_nhwc(
+            _ptr(x), _ptr(planes) if planes is not None else None, _ptr(f32) if f32 is not None else None, b, c, h * w,
+            self.mode, _stream()))
+        _abi.check(code, 'um_nchw_to_nhwc')
+        return planes, f32
+
     # ------------------------------------------------------------------ global matching
     def global_corr_softmax_flow(self, f0, f1, h, w, bidir=False):
         b, l, c = f0.shape
