@@ -1,7 +1,7 @@
 """Micro-benchmark of the HIP entry points at BASELINE sizes (GPU box).  Kernel time comes from the library's
 own hipEvents (um_timing_*), so split/convert pre-passes are reported separately from the main kernels.
 
-    python tools/bench_ops.py [attn] [gsv] [local] [linear] [--iters N] [--precision exact|fast] [--quick]
+    python tools/bench_ops.py [attn] [gsv] [local] [linear] [conv] [--iters N] [--precision exact|fast] [--quick]
 """
 import ctypes
 import os
@@ -51,7 +51,7 @@ def main():
     args = sys.argv[1:]
     iters = int(args[args.index('--iters') + 1]) if '--iters' in args else 10
     prec = args[args.index('--precision') + 1] if '--precision' in args else 'exact'
-    what = [a for a in args if a in ('attn', 'gsv', 'local', 'linear')] or ['attn', 'gsv', 'local', 'linear']
+    what = [a for a in args if a in ('attn', 'gsv', 'local', 'linear', 'conv')] or ['attn', 'gsv', 'local', 'linear', 'conv']
     ops = HipOps(prec)
     lib = _abi.load()
     issued = 3.0 if prec == 'exact' else 1.0
@@ -96,6 +96,31 @@ def main():
             2.0 * M * 8 * C * C, lib, iters, 'linear', issued)
         run('ffn fused    f32[M,128]x2 -> LN+res f32[M,128]', lambda: ops.ffn_ln(x, y, w1, w2, norm),
             2.0 * M * 8 * C * 3 * C, lib, iters, 'ffn', issued)
+    if 'conv' in what:
+        # encoder convolutions at config 2 (16 images): implicit GEMM on planes vs MIOpen fp32 on the same tensors
+        import time
+        for (cin, cout, hh, ww, st, tag) in ((64, 64, 256, 384, 1, 'layer1 3x3 64->64 @256x384'),
+                                             (64, 96, 256, 384, 2, 'layer2 3x3/2 64->96'),
+                                             (96, 96, 128, 192, 1, 'layer2 3x3 96->96 @128x192'),
+                                             (96, 128, 128, 192, 2, 'layer3 3x3/2 96->128'),
+                                             (128, 128, 64, 96, 1, 'layer3 3x3 128->128 @64x96')):
+            nb = 16
+            xin = torch.randn(nb, cin, hh, ww, device=dev, generator=g)
+            wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * 0.05
+            planes, _ = ops.nchw_to_nhwc(xin, want_planes=True, want_f32=False)
+            ho, wo = (hh - 1) // st + 1, (ww - 1) // st + 1
+            fl = 2.0 * nb * ho * wo * cout * 9 * cin
+            run(f'conv {tag}', lambda: ops.conv2d_nhwc((planes, nb, hh, ww, cin), wt, None, st, (1, 1)), fl, lib, iters,
+                'conv', issued)
+            for _ in range(3):
+                torch.nn.functional.conv2d(xin, wt, None, stride=st, padding=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                torch.nn.functional.conv2d(xin, wt, None, stride=st, padding=1)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            print(f'     MIOpen fp32 same conv                       {ms:8.4f} ms     {fl / ms / 1e9:8.1f} TF/s', flush=True)
     if 'gsv' in what:
         B, h, w = 8, 64, 96
         L = h * w

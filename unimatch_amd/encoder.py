@@ -35,6 +35,26 @@ class _Residual(nn.Module):
         return F.relu((x if self.downsample is None else self.downsample(x)) + y)
 
 
+    def forward_nhwc(self, act, ops, want_f32):
+        """Channels-last path on the matrix cores: ``act = (planes, f32, b, h, w, c)`` (operand planes of the block input
+        and, when the shortcut is the identity, its fp32 copy).  Every normalisation kernel writes the next convolution's
+        operand planes directly; ``want_f32`` asks for an fp32 copy of the output as well (identity shortcut downstream)."""
+        planes, f32, b, h, w, c = act
+        stride = self.conv1.stride[0]
+        cout = self.conv1.out_channels
+        t, ho, wo = ops.conv2d_nhwc((planes, b, h, w, c), self.conv1.weight, None, stride, (1, 1))
+        tp, _ = ops.nhwc_norm(t, b, ho * wo, relu=True, want_planes=True)
+        u, _, _ = ops.conv2d_nhwc((tp, b, ho, wo, cout), self.conv2.weight, None, 1, (1, 1))
+        if self.downsample is None:
+            sc = f32
+        else:
+            proj = self.downsample[0]
+            d, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), proj.weight, proj.bias, stride, (0, 0))
+            _, sc = ops.nhwc_norm(d, b, ho * wo, relu=False, want_planes=False, want_f32=True)
+        op, of = ops.nhwc_norm(u, b, ho * wo, relu=True, shortcut=sc, want_planes=True, want_f32=want_f32)
+        return op, of, b, ho, wo, cout
+
+
 class _SharedStridedConv(nn.Module):
     """One 3x3 weight applied at strides 1, 2, 4... ("trident" multi-scale branches, no bias)."""
 
@@ -46,6 +66,14 @@ class _SharedStridedConv(nn.Module):
 
     def forward(self, x):
         return [F.conv2d(x, self.weight, None, stride=2 ** i, padding=1) for i in range(self.num_branch)]
+
+    def forward_nhwc(self, act, ops):
+        planes, _, b, h, w, c = act
+        outs = []
+        for i in range(self.num_branch):
+            o, ho, wo = ops.conv2d_nhwc((planes, b, h, w, c), self.weight, None, 2 ** i, (1, 1))
+            outs.append(o.view(b, ho, wo, -1).permute(0, 3, 1, 2))
+        return outs
 
 
 class CNNEncoder(nn.Module):
@@ -72,6 +100,8 @@ class CNNEncoder(nn.Module):
     def forward(self, x, ops=None):
         """``ops``: a backend offering ``instance_norm`` (HipOps) fuses the normalisation / activation tail of
         every convolution; ``None`` keeps the stock PyTorch modules (CPU tests)."""
+        if ops is not None and getattr(ops, 'fused_conv', False) and x.is_cuda:
+            return self._forward_nhwc(x, ops)
         if ops is not None and getattr(ops, 'fused_tail', False) and x.is_cuda:
             x = ops.instance_norm(self.conv1(x), relu=True)
             for layer in (self.layer1, self.layer2, self.layer3):
@@ -82,3 +112,23 @@ class CNNEncoder(nn.Module):
             x = F.relu(self.norm1(self.conv1(x)))
             x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return self.trident_conv(x) if self.num_branch > 1 else [x]       # high -> low resolution
+
+
+    def _forward_nhwc(self, x, ops):
+        """Everything after the 7x7 stem in channels-last layout on the library's convolution / normalisation kernels
+        (``um_conv2d_fwd``, ``um_nhwc_instance_norm``).  The returned maps are NCHW *views* of NHWC memory, so
+        ``flatten(2).transpose(1, 2)`` downstream (token-major features) is free."""
+        y = ops.instance_norm(self.conv1(x), relu=True)                 # stem: MIOpen + fused norm, NCHW
+        b, c, h, w = y.shape
+        planes, f32 = ops.nchw_to_nhwc(y, want_planes=True, want_f32=True)
+        act = (planes, f32, b, h, w, c)
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3) for blk in layer]
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            act = blk.forward_nhwc(act, ops, want_f32=nxt is not None and nxt.downsample is None)
+        planes, _, b, h, w, c = act
+        out, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), self.conv2.weight, self.conv2.bias, 1, (0, 0))
+        if self.num_branch == 1:
+            return [out.view(b, h, w, -1).permute(0, 3, 1, 2)]
+        tp, _ = ops.nhwc_norm(out, b, h * w, normalize=False, relu=False, want_planes=True)
+        return self.trident_conv.forward_nhwc((tp, None, b, h, w, out.shape[1]), ops)

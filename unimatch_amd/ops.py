@@ -56,6 +56,8 @@ class HipOps:
 
     fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
+    fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
+    CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
     WSHIFT = 10                # weights are scaled by 2^10 before the fp16 split (exact), see linear.hip
 
     def __init__(self, precision='exact'):
@@ -242,8 +244,8 @@ class HipOps:
             return hit
         cout, cin, kh, kw = weight.shape
         w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous()
-        planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, self.mode), dtype=torch.uint8, device=w2.device)
-        _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, self.mode, _stream()),
+        planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, self.CONV_MODE), dtype=torch.uint8, device=w2.device)
+        _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, self.CONV_MODE, _stream()),
                    'um_weight_planes')
         if len(self._wcache) > 256:
             self._wcache.clear()
@@ -262,7 +264,7 @@ class HipOps:
         meta = {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin}
         code = self._launch('conv', lambda: self.lib.um_conv2d_fwd(
             _ptr(planes), _ptr(wp), _ptr(bias) if bias is not None else None, _ptr(out), b, h, w, cin, cout, kh, kw,
-            stride, ph, pw, int(bool(relu)), self.WSHIFT, self.mode, _stream()), meta)
+            stride, ph, pw, int(bool(relu)), self.WSHIFT, self.CONV_MODE, _stream()), meta)
         _abi.check(code, 'um_conv2d_fwd')
         return out, ho, wo
 
@@ -275,14 +277,14 @@ class HipOps:
         if shortcut is not None:
             self._check_rows('shortcut', shortcut, c)
         rows = b * pixels
-        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.mode), dtype=torch.uint8, device=x.device)
+        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.CONV_MODE), dtype=torch.uint8, device=x.device)
                   if want_planes else None)
         f32 = torch.empty_like(x) if want_f32 else None
         ws = self._ws(self.lib.um_nhwc_norm_workspace_bytes(b, pixels, c), x.device) if normalize else None
         code = self._launch('instance_norm', lambda: self.lib.um_nhwc_instance_norm(
             _ptr(x), _ptr(shortcut) if shortcut is not None else None, _ptr(planes) if planes is not None else None,
             _ptr(f32) if f32 is not None else None, b, pixels, c, float(eps), int(bool(normalize)), int(bool(relu)),
-            _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.mode, _stream()))
+            _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
         _abi.check(code, 'um_nhwc_instance_norm')
         return planes, f32
 
@@ -292,12 +294,12 @@ class HipOps:
             raise ValueError('nchw_to_nhwc: expected a contiguous CUDA float32 NCHW tensor')
         b, c, h, w = x.shape
         rows = b * h * w
-        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.mode), dtype=torch.uint8, device=x.device)
+        planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.CONV_MODE), dtype=torch.uint8, device=x.device)
                   if want_planes else None)
         f32 = torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
         code = self._launch('instance_norm', lambda: self.lib.um_nchw_to_nhwc(
             _ptr(x), _ptr(planes) if planes is not None else None, _ptr(f32) if f32 is not None else None, b, c, h * w,
-            self.mode, _stream()))
+            self.CONV_MODE, _stream()))
         _abi.check(code, 'um_nchw_to_nhwc')
         return planes, f32
 
