@@ -49,7 +49,8 @@ const char* um_last_error_string(void);
 /* Optional measurement aid: when enabled, every launch of the kernels below is bracketed by a pair of
  * hipEvents recorded on the launch stream itself; um_timing_collect() waits for them, returns the summed
  * kernel time and launch count since the last collect, and recycles the events.  Off by default (then the
- * library keeps no state at all). */
+ * library keeps no state at all).  Two event records per launch are not free (~6 % of a 14 ms forward with every
+ * kernel timed): select only the kernels of interest inside a timed region. */
 #define UM_K_WINDOW_ATTN 0   /* window_attn_kernel (um_window_attn_fwd)                                  */
 #define UM_K_GLOBAL_SOFTMAX 1 /* gsv_kernel (um_global_corr_softmax_flow/_stereo, um_prop_global_attn)    */
 #define UM_K_SPLIT_PLANES 2  /* split_planes_kernel (operand conversion pre-pass of the MFMA kernels)     */
@@ -63,7 +64,7 @@ const char* um_last_error_string(void);
 #define UM_K_FFN 10          /* ffn_kernel (um_ffn_fwd)                                                  */
 #define UM_K_CONV 11         /* conv_kernel (um_conv2d_fwd)                                              */
 #define UM_K_COUNT 12
-int um_timing_enable(int on);
+int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
 /* ---------------------------------------------------------------------------------------------
@@ -134,9 +135,13 @@ int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void
  *   w_planes : um_weight_planes() of the weight permuted to [cout][kh][kw][cin] (n = cout, k = kh*kw*cin), same wshift.
  *   out      : fp32 [batch*ho*wo][cout] (NHWC), ho = (hi + 2 pad_h - kh) / stride + 1; + bias[cout] if not NULL; ReLU if relu.
  * ------------------------------------------------------------------------------------------- */
-int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, int batch, int hi, int wi,
-                  int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int wshift, int mode,
-                  void* stream);
+int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out, int batch,
+                  int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int wshift,
+                  int mode, void* stream);
+/* stats_out (optional, um_conv_stats_bytes() bytes, needs ho*wo % 128 == 0): per 128-pixel output tile the (mean, 0, sum of
+ * squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
+ * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */
+size_t um_conv_stats_bytes(int batch, int pixels, int channels);
 
 /* nn.InstanceNorm2d (affine=False, biased variance) + ReLU (+ shortcut add + ReLU) of unimatch/backbone.py:7-36 in NHWC:
  *   y = x (normalize == 0) | (x - mean_{b,c}) * rsqrt(var_{b,c} + eps);  y = relu(y) if relu;  y = relu(shortcut + y) if
@@ -145,8 +150,8 @@ int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias,
  * Statistics are deterministic (fixed reduction order, chunk-shifted sums merged in fp64).  channels: multiple of 8, <= 256. */
 size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channels);
 int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch, int pixels,
-                          int channels, float eps, int normalize, int relu, void* workspace, size_t workspace_bytes,
-                          int mode, void* stream);
+                          int channels, float eps, int normalize, int relu, const float* conv_stats, void* workspace,
+                          size_t workspace_bytes, int mode, void* stream);
 
 /* fp32 NCHW [batch][channels][pixels] (the output of a MIOpen convolution) -> NHWC operand planes (with the zero row)
  * and / or fp32 NHWC.  channels: multiple of 8, <= 256. */

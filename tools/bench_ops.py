@@ -33,7 +33,7 @@ def run(label, fn, flops, lib, iters, kernel, issued=1.0):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    lib.um_timing_enable(1)
+    lib.um_timing_enable(-1)
     collect(lib)
     for _ in range(iters):
         fn()

@@ -27,10 +27,11 @@ SIGNATURES = {
     'um_weight_planes': (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p]),
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),
     'um_ffn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
-    'um_conv2d_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 13 + [_c_void_p]),
+    'um_conv2d_fwd': (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_void_p]),
+    'um_conv_stats_bytes': (_c_size_t, [_c_int] * 3),
     'um_nhwc_norm_workspace_bytes': (_c_size_t, [_c_int] * 3),
-    'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_size_t,
-                                       _c_int, _c_void_p]),
+    'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_void_p,
+                                       _c_size_t, _c_int, _c_void_p]),
     'um_nchw_to_nhwc': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_convex_upsample': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
     'um_instance_norm_fwd': (_c_int, [_c_void_p] * 3 + [ctypes.c_long, _c_int, ctypes.c_float, _c_int, _c_void_p]),

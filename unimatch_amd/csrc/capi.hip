@@ -25,7 +25,7 @@ extern "C" const char* um_last_error_string(void) { return g_err; }
 namespace {
 struct TimingState {
     std::mutex mu;
-    bool on = false;
+    unsigned mask = 0;                     // bit k: kernel id k is timed
     std::vector<std::pair<hipEvent_t, hipEvent_t>> live[UM_K_COUNT];
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -42,10 +42,10 @@ struct TimingState {
 TimingState g_t;
 }  // namespace
 
-bool um_timing_on() { return g_t.on; }
+bool um_timing_on() { return g_t.mask != 0; }
 
 void* um_timing_begin(int kid, hipStream_t stream) {
-    if (!g_t.on || kid < 0 || kid >= UM_K_COUNT) return nullptr;
+    if (kid < 0 || kid >= UM_K_COUNT || !((g_t.mask >> kid) & 1u)) return nullptr;
     std::lock_guard<std::mutex> lk(g_t.mu);
     hipEvent_t a = g_t.get(), b = g_t.get();
     if (!a || !b) return nullptr;
@@ -58,9 +58,9 @@ void um_timing_end(void* token, hipStream_t stream) {
     if (token) (void)hipEventRecord((hipEvent_t)token, stream);
 }
 
-extern "C" int um_timing_enable(int on) {
+extern "C" int um_timing_enable(int kernel_mask) {
     std::lock_guard<std::mutex> lk(g_t.mu);
-    g_t.on = on != 0;
+    g_t.mask = (unsigned)kernel_mask;
     return 0;
 }
 

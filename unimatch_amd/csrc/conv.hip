@@ -26,6 +26,7 @@ struct ConvArgs {
     long w_plane_stride;
     const float* bias;            // [Cout] or null
     float* out;                   // [M][Cout]
+    float* stats;                 // optional [M / 128][3][Cout]: per 128-pixel tile (mean, 0, sum of squared deviations)
     int B, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad_h, pad_w;
     int M;                        // B * Ho * Wo
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     constexpr int TILE = 128 * 64;               // one 128-row x 64-byte operand tile (one plane, one stage)
     constexpr int STAGE = 2 * NS * TILE;         // activation planes then weight planes (sized for NT = 4)
     constexpr int EPI = 4 * 32 * (32 * NT * 4);   // the epilogue's transposed tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
+    constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 4 * 2 * 32 * NT * 4];   // + per-wave (mean, M2) columns
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,6 +194,43 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
         }
     __builtin_amdgcn_wave_barrier();
+    if (a.stats) {
+        // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
+        // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
+        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  Only used when tiles do not
+        // straddle images (pixels per image a multiple of 128), so every row is valid here.
+        float* ws = reinterpret_cast<float*>(lds + RING) + wave * (2 * 32 * NT);
+        for (int ch = lane; ch < 32 * NT; ch += 64) {
+            const int c = ch >> 2, ci = ch & 3;
+            const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const float d = *reinterpret_cast<const float*>(stg + r * ROWB + ((c ^ (r & 7)) << 4) + ci * 4) - k;
+                s1 += d;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+            ws[ch] = k + s1 * (1.0f / 32.0f);                               // mean of the wave's 32 pixels
+            ws[32 * NT + ch] = s2 - s1 * s1 * (1.0f / 32.0f);              // sum of squared deviations
+        }
+        __syncthreads();
+        if (tid < 32 * NT && n0 + tid < a.Cout) {
+            const float* w0 = reinterpret_cast<const float*>(lds + RING);
+            float mean = w0[tid], m2 = w0[32 * NT + tid], n = 32.f;
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
+                const float delta = mw - mean, nn = n + 32.f;
+                mean += delta * (32.f / nn);
+                m2 += m2w + delta * delta * (n * 32.f / nn);
+                n = nn;
+            }
+            float* pr = a.stats + ((long)blockIdx.x * 3) * a.Cout + n0 + tid;
+            pr[0] = mean;
+            pr[a.Cout] = 0.f;
+            pr[2 * a.Cout] = m2;
+        }
+    }
     constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
     constexpr int ITER = 32 * CPR / 64;
     const int row0 = m0 + 32 * wave;
@@ -219,9 +258,9 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
     return hipGetLastError();
 }
 
-extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, int batch, int hi,
-                             int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu,
-                             int wshift, int mode, void* stream_) {
+extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,
+                             int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w,
+                             int relu, int wshift, int mode, void* stream_) {
     if (!a_planes || !w_planes || !out || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 || cout <= 0 ||
         cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) || wshift < 0 ||
         wshift > 14) {
@@ -235,6 +274,10 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
         return -1;
     }
     const long rows_in = (long)batch * hi * wi, m = (long)batch * ho * wo;
+    if (stats_out && ((long)ho * wo) % 128 != 0) {
+        um_set_error("um_conv2d_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+        return -1;
+    }
     if ((rows_in + 1) * cin * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
         um_set_error("um_conv2d_fwd: operand planes beyond 4 GiB are not addressable by this kernel");
         return -4;
@@ -246,6 +289,7 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
     a.w_plane_stride = (long)cout * kh * kw * cin;
     a.bias = bias;
     a.out = out;
+    a.stats = stats_out;
     a.B = batch;
     a.Hi = hi;
     a.Wi = wi;

@@ -12,7 +12,7 @@
 #include "common.h"
 #include "planes.h"
 
-#define NHWC_CHUNK_ROWS 1024
+#define NHWC_CHUNK_ROWS 4096
 
 // ---- pass 1: per-chunk shifted sums.  grid (chunks, B), block 256; thread = (row lane, channel quad) --------------
 __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* partial, int P, int C, int nchunk) {
@@ -52,25 +52,46 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* 
     }
 }
 
-// ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd.  grid B, block C ----
-__global__ void nhwc_stats_finalize_kernel(const float* partial, float* stats, int P, int C, int nchunk, float eps) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+// ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd.  grid B, block 256 ----
+// partial[b][part][3][C] = (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short):
+// written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS) or by conv_kernel's epilogue (rpp = 128, k = tile mean).
+__global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* partial, float* stats, int P, int C, int nparts,
+                                                                  int rpp, float eps) {
+    __shared__ double red[3][256];
+    const int b = blockIdx.x;
+    const int lanes = 256 / C > 0 ? 256 / C : 1;                  // threads per channel (C <= 256)
+    const int c = threadIdx.x % C, ln = threadIdx.x / C;
     double n_tot = 0.0, mean = 0.0, m2 = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float* pr = partial + (((long)b * nchunk + ch) * 3) * C;
-        const int r0 = ch * NHWC_CHUNK_ROWS;
-        const double n = (double)(min(P, r0 + NHWC_CHUNK_ROWS) - r0);
-        const double k = pr[c], s1 = pr[C + c], s2 = pr[2 * C + c];
-        const double mc = k + s1 / n, m2c = s2 - s1 * s1 / n;
-        const double delta = mc - mean, nn = n_tot + n;
-        mean += delta * n / nn;
-        m2 += m2c + delta * delta * n_tot * n / nn;
-        n_tot = nn;
+    if (ln < lanes) {
+        for (int pt = ln; pt < nparts; pt += lanes) {
+            const float* pr = partial + (((long)b * nparts + pt) * 3) * C;
+            const int r0 = pt * rpp;
+            const double n = (double)(min(P, r0 + rpp) - r0);
+            const double k = pr[c], s1 = pr[C + c], s2 = pr[2 * C + c];
+            const double mc = k + s1 / n, m2c = s2 - s1 * s1 / n;
+            const double delta = mc - mean, nn = n_tot + n;
+            mean += delta * n / nn;
+            m2 += m2c + delta * delta * n_tot * n / nn;
+            n_tot = nn;
+        }
     }
-    const double var = m2 / n_tot;                                // biased, as nn.InstanceNorm2d
-    stats[((long)b * 2) * C + c] = (float)mean;
-    stats[((long)b * 2 + 1) * C + c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    red[0][threadIdx.x] = n_tot;
+    red[1][threadIdx.x] = mean;
+    red[2][threadIdx.x] = m2;
+    __syncthreads();
+    if (ln == 0) {
+        for (int l = 1; l < lanes; ++l) {                          // fixed order: deterministic
+            const double n = red[0][l * C + c], mc = red[1][l * C + c], m2c = red[2][l * C + c];
+            if (n == 0.0) continue;
+            const double delta = mc - mean, nn = n_tot + n;
+            mean += delta * n / nn;
+            m2 += m2c + delta * delta * n_tot * n / nn;
+            n_tot = nn;
+        }
+        const double var = m2 / n_tot;                            // biased, as nn.InstanceNorm2d
+        stats[((long)b * 2) * C + c] = (float)mean;
+        stats[((long)b * 2 + 1) * C + c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
 }
 
 // ---- pass 3: apply.  One thread = 8 channels of one pixel (16 bytes of every output plane).  ----------------------
@@ -198,11 +219,16 @@ extern "C" size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channe
     return (size_t)((long)batch * nchunk * 3 * channels + (long)batch * 2 * channels) * sizeof(float);
 }
 
+extern "C" size_t um_conv_stats_bytes(int batch, int pixels, int channels) {
+    if (batch <= 0 || pixels <= 0 || channels <= 0 || pixels % 128 != 0) return 0;
+    return (size_t)((long)batch * (pixels / 128) * 3 * channels) * sizeof(float);
+}
+
 static bool nhwc_channels_ok(int c) { return c > 0 && c % 8 == 0 && c <= 256; }
 
 extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch,
-                                     int pixels, int channels, float eps, int normalize, int relu, void* workspace,
-                                     size_t workspace_bytes, int mode, void* stream_) {
+                                     int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats,
+                                     void* workspace, size_t workspace_bytes, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || (!planes_out && !f32_out) || batch <= 0 || pixels <= 0 || !nhwc_channels_ok(channels) || (mode != 0 && mode != 1)) {
         um_set_error("um_nhwc_instance_norm: bad argument (batch=%d pixels=%d channels=%d: channels must be a multiple of 8, <= 256)",
@@ -220,9 +246,18 @@ extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void
             return -3;
         }
         stats = partial + (long)batch * nchunk * 3 * channels;
-        hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, partial, pixels, channels, nchunk);
-        hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(batch), dim3(256), 0, stream, partial, stats, pixels, channels,
-                           nchunk, eps);
+        if (conv_stats) {                                          // per-128-pixel tile statistics from um_conv2d_fwd
+            if (pixels % 128 != 0) {
+                um_set_error("um_nhwc_instance_norm: conv_stats need pixels %% 128 == 0");
+                return -1;
+            }
+            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(batch), dim3(256), 0, stream, conv_stats, stats, pixels, channels,
+                               pixels / 128, 128, eps);
+        } else {
+            hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, partial, pixels, channels, nchunk);
+            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(batch), dim3(256), 0, stream, partial, stats, pixels, channels,
+                               nchunk, NHWC_CHUNK_ROWS, eps);
+        }
     }
     const long total = (rows + (planes_out ? 1 : 0)) * (channels / 8);
     const dim3 grid((unsigned)((total + 255) / 256));

@@ -42,16 +42,17 @@ class _Residual(nn.Module):
         planes, f32, b, h, w, c = act
         stride = self.conv1.stride[0]
         cout = self.conv1.out_channels
-        t, ho, wo = ops.conv2d_nhwc((planes, b, h, w, c), self.conv1.weight, None, stride, (1, 1))
-        tp, _ = ops.nhwc_norm(t, b, ho * wo, relu=True, want_planes=True)
-        u, _, _ = ops.conv2d_nhwc((tp, b, ho, wo, cout), self.conv2.weight, None, 1, (1, 1))
+        t, ho, wo = ops.conv2d_nhwc((planes, b, h, w, c), self.conv1.weight, None, stride, (1, 1), stats=True)
+        tp, _ = ops.nhwc_norm(t, b, ho * wo, relu=True, want_planes=True, conv_stats=ops.last_conv_stats)
+        u, _, _ = ops.conv2d_nhwc((tp, b, ho, wo, cout), self.conv2.weight, None, 1, (1, 1), stats=True)
+        ustats = ops.last_conv_stats
         if self.downsample is None:
             sc = f32
         else:
             proj = self.downsample[0]
-            d, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), proj.weight, proj.bias, stride, (0, 0))
-            _, sc = ops.nhwc_norm(d, b, ho * wo, relu=False, want_planes=False, want_f32=True)
-        op, of = ops.nhwc_norm(u, b, ho * wo, relu=True, shortcut=sc, want_planes=True, want_f32=want_f32)
+            d, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), proj.weight, proj.bias, stride, (0, 0), stats=True)
+            _, sc = ops.nhwc_norm(d, b, ho * wo, relu=False, want_planes=False, want_f32=True, conv_stats=ops.last_conv_stats)
+        op, of = ops.nhwc_norm(u, b, ho * wo, relu=True, shortcut=sc, want_planes=True, want_f32=want_f32, conv_stats=ustats)
         return op, of, b, ho, wo, cout
 
 

@@ -5,6 +5,8 @@ shapes / dtypes / contiguity, allocates the output (and scratch workspace) as to
 the HIP kernels on torch's current stream through ``ctypes``.  Feature tensors are token-major
 ``[N, L, C]`` fp32 (C = 128); flow-like tensors are ``[N, V, h, w]`` fp32 as in the reference.
 """
+import weakref
+
 import torch
 
 from . import _abi
@@ -105,10 +107,27 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ fused Transformer-layer tail
+    def _cache_get(self, tag, tensors):
+        """Cached value for these tensor OBJECTS at their current versions.  Keyed by identity and validated through weak
+        references: a ``data_ptr`` key is wrong for temporaries (the allocator hands a freed weight's address to the next
+        tensor of the same shape)."""
+        key = (tag,) + tuple((id(t), t._version) for t in tensors)
+        hit = self._wcache.get(key)
+        if hit is not None and all(r() is t for r, t in zip(hit[0], tensors)):
+            return key, hit[1]
+        return key, None
+
+    def _cache_put(self, key, tensors, value):
+        if len(self._wcache) > 256:
+            self._wcache = {k: v for k, v in self._wcache.items() if all(r() is not None for r in v[0])}
+            if len(self._wcache) > 256:
+                self._wcache.clear()
+        self._wcache[key] = (tuple(weakref.ref(t) for t in tensors), value)
+        return value
+
     def weight_planes(self, weights):
         """MFMA operand planes of ``cat(weights, 0)`` ([N, K] fp32 each, same K), cached until a weight changes."""
-        key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
-        hit = self._wcache.get(key)
+        key, hit = self._cache_get('lin', weights)
         if hit is not None:
             return hit
         w = (weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)).detach().float().contiguous()
@@ -116,10 +135,7 @@ class HipOps:
         planes = torch.empty(self.lib.um_planes_bytes(n, k, self.mode), dtype=torch.uint8, device=w.device)
         _abi.check(self.lib.um_weight_planes(_ptr(w), _ptr(planes), n, k, self.WSHIFT, self.mode, _stream()),
                    'um_weight_planes')
-        if len(self._wcache) > 256:
-            self._wcache.clear()
-        self._wcache[key] = (planes, n, k)
-        return self._wcache[key]
+        return self._cache_put(key, weights, (planes, n, k))
 
     def _check_rows(self, name, t, k):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.shape[1] == k):
@@ -238,8 +254,7 @@ class HipOps:
     #   f32   : fp32 [rows, C] or None;   b, h, w, c: geometry, rows = b * h * w
     def conv_weight_planes(self, weight):
         """Planes of an ``nn.Conv2d`` weight ``[cout, cin, kh, kw]`` permuted to ``[cout, kh*kw*cin]``; cached."""
-        key = ('conv', weight.data_ptr(), weight._version, tuple(weight.shape))
-        hit = self._wcache.get(key)
+        key, hit = self._cache_get('conv', (weight,))
         if hit is not None:
             return hit
         cout, cin, kh, kw = weight.shape
@@ -247,13 +262,11 @@ class HipOps:
         planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, self.CONV_MODE), dtype=torch.uint8, device=w2.device)
         _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, self.CONV_MODE, _stream()),
                    'um_weight_planes')
-        if len(self._wcache) > 256:
-            self._wcache.clear()
-        self._wcache[key] = (planes, cout, cin, kh, kw)
-        return self._wcache[key]
+        return self._cache_put(key, (weight,), (planes, cout, cin, kh, kw))
 
-    def conv2d_nhwc(self, act, weight, bias=None, stride=1, padding=(1, 1), relu=False):
-        """``act``: ``(planes, b, h, w, cin)``; returns fp32 ``[b*ho*wo, cout]`` and ``(ho, wo)``."""
+    def conv2d_nhwc(self, act, weight, bias=None, stride=1, padding=(1, 1), relu=False, stats=False):
+        """``act``: ``(planes, b, h, w, cin)``; returns fp32 ``[b*ho*wo, cout]`` and ``(ho, wo)``.  With ``stats`` (and
+        ``ho*wo % 128 == 0``) the epilogue also emits the per-tile InstanceNorm statistics: ``self.last_conv_stats``."""
         planes, b, h, w, cin = act
         wp, cout, wcin, kh, kw = self.conv_weight_planes(weight)
         if wcin != cin:
@@ -261,14 +274,21 @@ class HipOps:
         ph, pw = (padding, padding) if isinstance(padding, int) else padding
         ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
         out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=planes.device)
+        self.last_conv_stats = None
+        if stats and (ho * wo) % 128 == 0:
+            self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
+                                               device=planes.device)
+        st = self.last_conv_stats
         meta = {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin}
         code = self._launch('conv', lambda: self.lib.um_conv2d_fwd(
-            _ptr(planes), _ptr(wp), _ptr(bias) if bias is not None else None, _ptr(out), b, h, w, cin, cout, kh, kw,
+            _ptr(planes), _ptr(wp), _ptr(bias) if bias is not None else None, _ptr(out), _ptr(st) if st is not None else None,
+            b, h, w, cin, cout, kh, kw,
             stride, ph, pw, int(bool(relu)), self.WSHIFT, self.CONV_MODE, _stream()), meta)
         _abi.check(code, 'um_conv2d_fwd')
         return out, ho, wo
 
-    def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5):
+    def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5,
+                  conv_stats=None):
         """InstanceNorm (+ ReLU, + shortcut + ReLU) of fp32 NHWC ``x [b*pixels, c]`` -> ``(planes | None, f32 | None)``."""
         self._check_rows('x', x, x.shape[1])
         c = x.shape[1]
@@ -284,7 +304,7 @@ class HipOps:
         code = self._launch('instance_norm', lambda: self.lib.um_nhwc_instance_norm(
             _ptr(x), _ptr(shortcut) if shortcut is not None else None, _ptr(planes) if planes is not None else None,
             _ptr(f32) if f32 is not None else None, b, pixels, c, float(eps), int(bool(normalize)), int(bool(relu)),
-            _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
+            _ptr(conv_stats) if conv_stats is not None else None, _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
         _abi.check(code, 'um_nhwc_instance_norm')
         return planes, f32
 
