@@ -143,6 +143,17 @@ int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias,
  * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */
 size_t um_conv_stats_bytes(int batch, int pixels, int channels);
 
+/* The encoder's 7x7 / stride-2 / pad-3 stem (unimatch/backbone.py:49; 3 input channels, no bias) on the same kernel, always
+ * in the exact arithmetic.  image: fp32 NCHW [batch,3,h,w]; with `normalize` the reference's input normalisation
+ * ((x / 255 - mean) / std, unimatch/unimatch.py:122-124) is applied while packing.  image_planes: scratch of
+ * um_stem_planes_bytes() bytes (the zero-bordered NHWC-4 operand planes).  w_planes: um_weight_planes() of the weight
+ * rearranged to [cout][7 ky][8 kx][4 ci] with zeros at kx = 7 and ci = 3 (n = cout, k = 224).  out: fp32 NHWC
+ * [batch * ho * wo][cout], ho = (h - 1) / 2 + 1.  stats_out: as um_conv2d_fwd. */
+size_t um_stem_planes_bytes(int batch, int h, int w);
+int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, const float* std3, void* image_planes,
+                     const void* w_planes, float* out, float* stats_out, int batch, int h, int w, int cout, int wshift,
+                     void* stream);
+
 /* nn.InstanceNorm2d (affine=False, biased variance) + ReLU (+ shortcut add + ReLU) of unimatch/backbone.py:7-36 in NHWC:
  *   y = x (normalize == 0) | (x - mean_{b,c}) * rsqrt(var_{b,c} + eps);  y = relu(y) if relu;  y = relu(shortcut + y) if
  * shortcut.  x, shortcut: fp32 [batch*pixels][channels].  Outputs (either may be NULL): operand planes

@@ -418,6 +418,24 @@ def test_conv2d_nhwc_matches_fp64(ops, case):
     assert err(got, want)[0] < 3e-6 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('bhw,normalize', [((2, 64, 96), True), ((1, 37, 51), False), ((3, 16, 32), True)])
+def test_stem_conv_matches_fp64(ops, bhw, normalize):
+    """um_stem_conv_fwd: the 7x7 / stride 2 / pad 3 stem through the packed NHWC-4 image planes against torch conv2d in
+    fp64 (even and odd sizes), with and without the reference's input normalisation folded into the packing."""
+    b, h, w = bhw
+    img = rnd(99, b, 3, h, w).abs() * 120.0 if normalize else rnd(99, b, 3, h, w, scale=2.0)
+    wt = rnd(100, 64, 3, 7, 7, scale=0.12)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    x = img.double()
+    if normalize:
+        x = (x / 255.0 - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
+    want = torch.nn.functional.conv2d(x, wt.double(), None, stride=2, padding=3)
+    got, ho, wo = ops.stem_conv(img.to(DEV).contiguous(), wt.to(DEV), (mean, std) if normalize else None)
+    assert (ho, wo) == tuple(want.shape[-2:])
+    got = got.view(b, ho, wo, 64).permute(0, 3, 1, 2)
+    assert err(got, want)[0] < 4e-6 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize('cout,hw', [(64, (16, 24)), (96, (32, 12)), (256, (8, 16))])
 def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw):
     """um_conv2d_fwd(stats_out) -> um_nhwc_instance_norm(conv_stats): the per-tile statistics written by the convolution's

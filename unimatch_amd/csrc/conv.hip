@@ -22,6 +22,9 @@
 struct ConvArgs {
     const unsigned short* ap;     // [NS][rows_in + 1][Cin], row rows_in = zeros
     long a_plane_stride;
+    unsigned row_stride;          // bytes between consecutive input "rows" (pixels): Cin * 2, or less when the Cin
+                                  // contiguous elements of a tap span several packed pixels (the stem, um_stem_conv_fwd)
+    unsigned zero_row;            // row index of the all-zero row
     const unsigned short* wp;     // [NS][Cout][taps * Cin]
     long w_plane_stride;
     const float* bias;            // [Cout] or null
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         px[i] = x * a.stride - a.pad_w;
         pbase[i] = b * a.Hi * a.Wi;
     }
-    const unsigned zero_row = (unsigned)a.B * a.Hi * a.Wi;
+    const unsigned zero_row = a.zero_row;
     unsigned rowoff[2];                          // byte offset of the source row of the tap being staged
     auto set_tap = [&](int ky, int kx) {
 #pragma unroll
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             const int iy = py[i] + ky, ix = px[i] + kx;
             const bool ok = pok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
             const unsigned row = ok ? (unsigned)(pbase[i] + iy * a.Wi + ix) : zero_row;
-            rowoff[i] = row * (unsigned)(a.Cin * 2);
+            rowoff[i] = row * a.row_stride;
         }
     };
     // 16-byte chunk cp of row r holds source chunk cp ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
@@ -285,6 +288,8 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
     ConvArgs a;
     a.ap = (const unsigned short*)a_planes;
     a.a_plane_stride = (rows_in + 1) * cin;
+    a.row_stride = (unsigned)cin * 2;
+    a.zero_row = (unsigned)rows_in;
     a.wp = (const unsigned short*)w_planes;
     a.w_plane_stride = (long)cout * kh * kw * cin;
     a.bias = bias;
@@ -313,6 +318,109 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
     else e = launch_conv<4>(a, mode, (hipStream_t)stream_);
     if (e != hipSuccess) {
         um_set_error("um_conv2d_fwd: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ---- the 7x7 / stride-2 stem (unimatch/backbone.py:49, 3 -> 64 channels) on the same kernel ------------------------------
+// The image is packed once into zero-bordered NHWC-4 planes [NS][B][H + 6][Wp][4] (channel 3 = 0, Wp = W + 6 rounded up to
+// even).  For output pixel (y, x) and kernel row ky the 7 taps x 3 channels are then 32 CONTIGUOUS elements starting at
+// packed pixel (2y + ky, 2x): pixels 2x .. 2x+7 x 4 channels, where the 8th pixel and the 4th channel meet zero weights.
+// So the stem is a "7 x 1 convolution with 32 input channels" whose rows advance by one packed pixel (8 bytes): K = 224
+// instead of 147, no im2col, no border logic, 16-byte aligned LDS-DMA.
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, unsigned short* planes, long plane_stride, int B,
+                                                        int H, int W, int Hp, int Wp, int normalize, float m0, float m1,
+                                                        float m2, float s0, float s1, float s2) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * Hp * Wp;
+    if (idx >= total) return;
+    const int xp = (int)(idx % Wp);
+    const long t = idx / Wp;
+    const int yp = (int)(t % Hp), b = (int)(t / Hp);
+    const int y = yp - 3, x = xp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+        const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p = img[(((long)b * 3 + c) * H + y) * W + x];
+            if (normalize) p = (p / 255.0f - mean[c]) / sd[c];        // the reference's operation order (unimatch.py:122-124)
+            v[c] = p;
+        }
+    }
+    const unsigned h0 = Fp16::pack2(v[0], v[1]), h1 = Fp16::pack2(v[2], 0.f);
+    *reinterpret_cast<u32x2*>(planes + idx * 4) = u32x2{h0, h1};
+    const f32x2 u0 = Fp16::unpack2(h0), u1 = Fp16::unpack2(h1);
+    *reinterpret_cast<u32x2*>(planes + plane_stride + idx * 4) =
+        u32x2{Fp16::pack2(v[0] - u0[0], v[1] - u0[1]), Fp16::pack2(v[2] - u1[0], 0.f)};
+}
+
+extern "C" size_t um_stem_planes_bytes(int batch, int h, int w) {
+    if (batch <= 0 || h <= 0 || w <= 0) return 0;
+    const long hp = h + 6, wp = (w + 6 + 1) & ~1L;
+    return (size_t)(2 * ((long)batch * hp * wp + 8) * 4 * 2);    // two fp16 planes, 8 pixels of slack
+}
+
+extern "C" int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, const float* std3, void* image_planes,
+                                const void* w_planes, float* out, float* stats_out, int batch, int h, int w, int cout,
+                                int wshift, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!image || !image_planes || !w_planes || !out || batch <= 0 || h < 7 || w < 7 || cout <= 0 || cout % 4 != 0 || wshift < 0 ||
+        wshift > 14 || (normalize && (!mean3 || !std3))) {
+        um_set_error("um_stem_conv_fwd: bad argument (batch=%d h=%d w=%d cout=%d)", batch, h, w, cout);
+        return -1;
+    }
+    const int hp = h + 6, wp = (w + 6 + 1) & ~1;
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;       // (h + 2*3 - 7) / 2 + 1
+    const long rows = (long)batch * hp * wp;
+    if (stats_out && ((long)ho * wo) % 128 != 0) {
+        um_set_error("um_stem_conv_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+        return -1;
+    }
+    if ((rows + 8) * 8 >= (1L << 32) || (long)batch * ho * wo >= (1L << 31)) {
+        um_set_error("um_stem_conv_fwd: image batch beyond the 32-bit addressing of this kernel");
+        return -4;
+    }
+    const long plane_stride = (rows + 8) * 4;
+    {
+        ScopedKernelTimer timer(UM_K_CONV, stream);
+        hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, image,
+                           (unsigned short*)image_planes, plane_stride, batch, h, w, hp, wp, normalize,
+                           normalize ? mean3[0] : 0.f, normalize ? mean3[1] : 0.f, normalize ? mean3[2] : 0.f,
+                           normalize ? std3[0] : 1.f, normalize ? std3[1] : 1.f, normalize ? std3[2] : 1.f);
+    }
+    ConvArgs a;
+    a.ap = (const unsigned short*)image_planes;
+    a.a_plane_stride = plane_stride;
+    a.row_stride = 8;                                             // one packed pixel
+    a.zero_row = 0;                                               // never used: every tap is inside the padded image
+    a.wp = (const unsigned short*)w_planes;
+    a.w_plane_stride = (long)cout * 224;
+    a.bias = nullptr;
+    a.out = out;
+    a.stats = stats_out;
+    a.B = batch;
+    a.Hi = hp;
+    a.Wi = wp;
+    a.Cin = 32;
+    a.Ho = ho;
+    a.Wo = wo;
+    a.Cout = cout;
+    a.KH = 7;
+    a.KW = 1;
+    a.stride = 2;
+    a.pad_h = 0;
+    a.pad_w = 0;
+    a.M = (int)((long)batch * ho * wo);
+    a.relu = 0;
+    a.out_scale = ldexpf(1.f, -wshift);
+    hipError_t e;
+    if (cout % 128 == 0) e = launch_conv<4>(a, 0, stream);
+    else if (cout % 96 == 0) e = launch_conv<3>(a, 0, stream);
+    else e = launch_conv<2>(a, 0, stream);
+    if (e != hipSuccess) {
+        um_set_error("um_stem_conv_fwd: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
     return 0;

@@ -98,11 +98,18 @@ class CNNEncoder(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
 
-    def forward(self, x, ops=None):
+    @staticmethod
+    def takes_raw_images(ops, x):
+        """True when the channels-last path will run: it folds the input normalisation into the stem's image packing."""
+        return ops is not None and getattr(ops, 'fused_conv', False) and x.is_cuda
+
+    def forward(self, x, ops=None, input_norm=None):
         """``ops``: a backend offering ``instance_norm`` (HipOps) fuses the normalisation / activation tail of
-        every convolution; ``None`` keeps the stock PyTorch modules (CPU tests)."""
-        if ops is not None and getattr(ops, 'fused_conv', False) and x.is_cuda:
-            return self._forward_nhwc(x, ops)
+        every convolution; ``None`` keeps the stock PyTorch modules (CPU tests).  ``input_norm = (mean3, std3)``: the
+        images are raw 0..255 and still need ``(x / 255 - mean) / std`` (only passed when ``takes_raw_images``)."""
+        if self.takes_raw_images(ops, x):
+            return self._forward_nhwc(x, ops, input_norm)
+        assert input_norm is None
         if ops is not None and getattr(ops, 'fused_tail', False) and x.is_cuda:
             x = ops.instance_norm(self.conv1(x), relu=True)
             for layer in (self.layer1, self.layer2, self.layer3):
@@ -115,13 +122,14 @@ class CNNEncoder(nn.Module):
         return self.trident_conv(x) if self.num_branch > 1 else [x]       # high -> low resolution
 
 
-    def _forward_nhwc(self, x, ops):
-        """Everything after the 7x7 stem in channels-last layout on the library's convolution / normalisation kernels
-        (``um_conv2d_fwd``, ``um_nhwc_instance_norm``).  The returned maps are NCHW *views* of NHWC memory, so
+    def _forward_nhwc(self, x, ops, input_norm=None):
+        """The whole encoder in channels-last layout on the library's convolution / normalisation kernels
+        (``um_stem_conv_fwd``, ``um_conv2d_fwd``, ``um_nhwc_instance_norm``).  The returned maps are NCHW *views* of NHWC memory, so
         ``flatten(2).transpose(1, 2)`` downstream (token-major features) is free."""
-        y = ops.instance_norm(self.conv1(x), relu=True)                 # stem: MIOpen + fused norm, NCHW
-        b, c, h, w = y.shape
-        planes, f32 = ops.nchw_to_nhwc(y, want_planes=True, want_f32=True)
+        b = x.shape[0]
+        y, h, w = ops.stem_conv(x.contiguous(), self.conv1.weight, input_norm, stats=True)    # fp32 NHWC [b*h*w, 64]
+        c = y.shape[1]
+        planes, f32 = ops.nhwc_norm(y, b, h * w, relu=True, want_planes=True, want_f32=True, conv_stats=ops.last_conv_stats)
         act = (planes, f32, b, h, w, c)
         blocks = [blk for layer in (self.layer1, self.layer2, self.layer3) for blk in layer]
         for i, blk in enumerate(blocks):

@@ -333,10 +333,14 @@ class UniMatch(nn.Module):
         dev = img0.device
 
         with torch.no_grad():
+            input_norm = None
             if task == 'flow':                  # stereo / depth loaders normalise already (unimatch.py:122-124)
-                mean, std = self._constants(dev)
-                img0, img1 = (img0 / 255. - mean) / std, (img1 / 255. - mean) / std
-            feats = self.backbone(torch.cat([img0, img1], 0), ops)[::-1]    # low -> high resolution
+                if self.backbone.takes_raw_images(ops, img0):
+                    input_norm = (_IMAGENET_MEAN, _IMAGENET_STD)            # folded into the stem's image packing
+                else:
+                    mean, std = self._constants(dev)
+                    img0, img1 = (img0 / 255. - mean) / std, (img1 / 255. - mean) / std
+            feats = self.backbone(torch.cat([img0, img1], 0), ops, input_norm)[::-1]    # low -> high resolution
             nb = img0.shape[0]
             flow, pred = None, None
             for s in range(self.num_scales):

@@ -5,6 +5,7 @@ shapes / dtypes / contiguity, allocates the output (and scratch workspace) as to
 the HIP kernels on torch's current stream through ``ctypes``.  Feature tensors are token-major
 ``[N, L, C]`` fp32 (C = 128); flow-like tensors are ``[N, V, h, w]`` fp32 as in the reference.
 """
+import ctypes
 import weakref
 
 import torch
@@ -285,6 +286,44 @@ class HipOps:
             b, h, w, cin, cout, kh, kw,
             stride, ph, pw, int(bool(relu)), self.WSHIFT, self.CONV_MODE, _stream()), meta)
         _abi.check(code, 'um_conv2d_fwd')
+        return out, ho, wo
+
+    def stem_conv(self, image, weight, norm_mean_std=None, stats=True):
+        """The encoder's 7x7/2 stem on ``um_stem_conv_fwd``: fp32 NCHW image ``[b,3,h,w]`` -> fp32 NHWC ``[b*ho*wo, cout]``.
+        ``norm_mean_std``: ``((m0,m1,m2), (s0,s1,s2))`` applies the reference's ``(x / 255 - mean) / std`` while packing."""
+        if not (image.is_cuda and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3
+                and image.is_contiguous()):
+            raise ValueError('stem_conv: expected a contiguous CUDA float32 [b, 3, h, w] image')
+        if tuple(weight.shape[1:]) != (3, 7, 7):
+            raise ValueError('stem_conv: expected a [cout, 3, 7, 7] weight')
+        b, _, h, w = image.shape
+        cout = weight.shape[0]
+        key, hit = self._cache_get('stem', (weight,))
+        if hit is None:
+            wr = torch.zeros((cout, 7, 8, 4), dtype=torch.float32, device=weight.device)
+            wr[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
+            wr = wr.reshape(cout, 224).contiguous()
+            wp = torch.empty(self.lib.um_planes_bytes(cout, 224, 0), dtype=torch.uint8, device=weight.device)
+            _abi.check(self.lib.um_weight_planes(_ptr(wr), _ptr(wp), cout, 224, self.WSHIFT, 0, _stream()), 'um_weight_planes')
+            hit = self._cache_put(key, (weight,), wp)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        scratch = torch.empty(self.lib.um_stem_planes_bytes(b, h, w), dtype=torch.uint8, device=image.device)
+        out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=image.device)
+        self.last_conv_stats = None
+        if stats and (ho * wo) % 128 == 0:
+            self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
+                                               device=image.device)
+        st = self.last_conv_stats
+        if norm_mean_std is not None:
+            mean = (ctypes.c_float * 3)(*[float(v) for v in norm_mean_std[0]])
+            std = (ctypes.c_float * 3)(*[float(v) for v in norm_mean_std[1]])
+        else:
+            mean = std = None
+        code = self._launch('conv', lambda: self.lib.um_stem_conv_fwd(
+            _ptr(image), int(norm_mean_std is not None), mean, std, _ptr(scratch), _ptr(hit), _ptr(out),
+            _ptr(st) if st is not None else None, b, h, w, cout, self.WSHIFT, _stream()),
+            {'flops': 2.0 * b * ho * wo * cout * 147})
+        _abi.check(code, 'um_stem_conv_fwd')
         return out, ho, wo
 
     def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5,
