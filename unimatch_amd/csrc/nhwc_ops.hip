@@ -52,37 +52,37 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* 
     }
 }
 
-// ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd.  grid B, block 256 ----
+// ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd ---------------------
 // partial[b][part][3][C] = (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short):
 // written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS) or by conv_kernel's epilogue (rpp = 128, k = tile mean).
+// grid (C / 8, B), block 256 = 8 channels x 32 lanes; every lane merges a strided subset of the parts, lane 0 merges the
+// lanes in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* partial, float* stats, int P, int C, int nparts,
                                                                   int rpp, float eps) {
     __shared__ double red[3][256];
-    const int b = blockIdx.x;
-    const int lanes = 256 / C > 0 ? 256 / C : 1;                  // threads per channel (C <= 256)
-    const int c = threadIdx.x % C, ln = threadIdx.x / C;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7), ln = threadIdx.x >> 3;
     double n_tot = 0.0, mean = 0.0, m2 = 0.0;
-    if (ln < lanes) {
-        for (int pt = ln; pt < nparts; pt += lanes) {
-            const float* pr = partial + (((long)b * nparts + pt) * 3) * C;
-            const int r0 = pt * rpp;
-            const double n = (double)(min(P, r0 + rpp) - r0);
-            const double k = pr[c], s1 = pr[C + c], s2 = pr[2 * C + c];
-            const double mc = k + s1 / n, m2c = s2 - s1 * s1 / n;
-            const double delta = mc - mean, nn = n_tot + n;
-            mean += delta * n / nn;
-            m2 += m2c + delta * delta * n_tot * n / nn;
-            n_tot = nn;
-        }
+    for (int pt = ln; pt < nparts; pt += 32) {
+        const float* pr = partial + (((long)b * nparts + pt) * 3) * C;
+        const int r0 = pt * rpp;
+        const double n = (double)(min(P, r0 + rpp) - r0);
+        const double k = pr[c], s1 = pr[C + c], s2 = pr[2 * C + c];
+        const double mc = k + s1 / n, m2c = s2 - s1 * s1 / n;
+        const double delta = mc - mean, nn = n_tot + n;
+        mean += delta * n / nn;
+        m2 += m2c + delta * delta * n_tot * n / nn;
+        n_tot = nn;
     }
     red[0][threadIdx.x] = n_tot;
     red[1][threadIdx.x] = mean;
     red[2][threadIdx.x] = m2;
     __syncthreads();
     if (ln == 0) {
-        for (int l = 1; l < lanes; ++l) {                          // fixed order: deterministic
-            const double n = red[0][l * C + c], mc = red[1][l * C + c], m2c = red[2][l * C + c];
+        for (int l = 1; l < 32; ++l) {
+            const double n = red[0][l * 8 + (threadIdx.x & 7)];
             if (n == 0.0) continue;
+            const double mc = red[1][l * 8 + (threadIdx.x & 7)], m2c = red[2][l * 8 + (threadIdx.x & 7)];
             const double delta = mc - mean, nn = n_tot + n;
             mean += delta * n / nn;
             m2 += m2c + delta * delta * n_tot * n / nn;
@@ -251,11 +251,11 @@ extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void
                 um_set_error("um_nhwc_instance_norm: conv_stats need pixels %% 128 == 0");
                 return -1;
             }
-            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(batch), dim3(256), 0, stream, conv_stats, stats, pixels, channels,
+            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, conv_stats, stats, pixels, channels,
                                pixels / 128, 128, eps);
         } else {
             hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, partial, pixels, channels, nchunk);
-            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(batch), dim3(256), 0, stream, partial, stats, pixels, channels,
+            hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, partial, stats, pixels, channels,
                                nchunk, NHWC_CHUNK_ROWS, eps);
         }
     }
