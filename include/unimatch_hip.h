@@ -234,7 +234,8 @@ int um_depth_corr_softmax(const float* f0, const float* f1, const float* cam, co
  * factor 4 or 8.
  * ------------------------------------------------------------------------------------------- */
 int um_convex_upsample(const float* flow, const float* mask, float* up, int batch, int channels, int h, int w,
-                       int factor, int is_depth, void* stream);
+                       int factor, int is_depth, int mask_nhwc, void* stream);
+/* mask_nhwc: the mask is [batch][h*w][9*factor^2] (the output of um_conv2d_fwd) instead of NCHW. */
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder helper (outside the hot path of SURVEY.md section 8; added because the element-wise tail of the CNN encoder

@@ -541,3 +541,6 @@ def test_convex_upsample(ops, cfg):
     want = om.convex_upsample(flow.double(), mask.double(), factor, is_depth=is_depth)
     got = ops.convex_upsample(flow.to(DEV), mask.to(DEV), factor, is_depth)
     assert got.shape == want.shape and err(got, want)[0] < 2e-6 * max(1.0, want.abs().max().item())
+    # the same mask in channels-last layout (what um_conv2d_fwd produces): bitwise the same result
+    nhwc = mask.permute(0, 2, 3, 1).reshape(b * h * w, -1).contiguous().to(DEV)
+    assert torch.equal(ops.convex_upsample(flow.to(DEV), nhwc, factor, is_depth, mask_nhwc=True), got)

@@ -14,7 +14,7 @@ template <int F, int V>
 __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ mask,
                                                               float* __restrict__ up, int batch, int h, int w,
-                                                              float mult) {
+                                                              float mult, long mask_cs, long mask_ps) {
     // one thread = one low-resolution pixel x one output sub-row fy: index = ((b*h + y)*F + fy)*w + x, so that a
     // wave reads 64 consecutive x of one mask channel (coalesced) and writes 64 x F consecutive outputs of one row
     const long total = (long)batch * h * F * w;
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 #pragma unroll
         for (int c = 0; c < V; ++c) nb[c][k] = ok ? mult * flow[((long)b * V + c) * L + yy * w + xx] : 0.f;
     }
-    const float* mb = mask + (long)b * 9 * F * F * L + (long)fy * F * L + p;
+    // mask element (b, channel, pixel) at b * 9 F^2 L + channel * mask_cs + pixel * mask_ps  (NCHW: L, 1; NHWC: 1, 9 F^2)
+    const float* mb = mask + (long)b * 9 * F * F * L + (long)fy * F * mask_cs + (long)p * mask_ps;
     float out[V][F];
 #pragma unroll
     for (int fx = 0; fx < F; ++fx) {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
         float mx = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            lg[k] = mb[(long)(k * F * F + fx) * L];
+            lg[k] = mb[(long)(k * F * F + fx) * mask_cs];
             mx = fmaxf(mx, lg[k]);
         }
         float den = 0.f, num[V];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 extern void um_set_error(const char* fmt, ...);
 
 extern "C" int um_convex_upsample(const float* flow, const float* mask, float* up, int batch, int channels, int h, int w,
-                                  int factor, int is_depth, void* stream_) {
+                                  int factor, int is_depth, int mask_nhwc, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!flow || !mask || !up || batch <= 0 || h <= 0 || w <= 0) {
         um_set_error("um_convex_upsample: null pointer or non-positive size");
@@ -84,14 +85,15 @@ extern "C" int um_convex_upsample(const float* flow, const float* mask, float* u
     const long total = (long)batch * h * w * factor;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     const float mult = is_depth ? 1.f : (float)factor;
+    const long cs = mask_nhwc ? 1 : (long)h * w, ps = mask_nhwc ? 9L * factor * factor : 1;
     ScopedKernelTimer timer(UM_K_CONVEX_UPSAMPLE, stream);
     if (factor == 8 && channels == 2)
-        hipLaunchKernelGGL((convex_upsample_kernel<8, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult);
+        hipLaunchKernelGGL((convex_upsample_kernel<8, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
     else if (factor == 8)
-        hipLaunchKernelGGL((convex_upsample_kernel<8, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult);
+        hipLaunchKernelGGL((convex_upsample_kernel<8, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
     else if (channels == 2)
-        hipLaunchKernelGGL((convex_upsample_kernel<4, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult);
+        hipLaunchKernelGGL((convex_upsample_kernel<4, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
     else
-        hipLaunchKernelGGL((convex_upsample_kernel<4, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult);
+        hipLaunchKernelGGL((convex_upsample_kernel<4, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
     return (int)hipGetLastError();
 }

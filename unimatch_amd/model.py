@@ -310,6 +310,19 @@ class UniMatch(nn.Module):
         return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
 
     def _upsample(self, flow2, f0_map, is_depth=False):
+        ops = self.ops
+        if getattr(ops, 'fused_conv', False) and flow2.is_cuda and self.upsample_factor in (4, 8):
+            # mask head on the library's convolutions, channels-last: cat(flow, feature) -> 3x3 + ReLU -> 1x1 -> NHWC mask
+            b, v, h, w = flow2.shape
+            rows = b * h * w
+            feat = f0_map.permute(0, 2, 3, 1).reshape(rows, -1)          # a view when f0_map came from tokens
+            planes, cin = ops.nhwc_planes_from([flow2.permute(0, 2, 3, 1).reshape(rows, v), feat])
+            c1, c2 = self.upsampler[0], self.upsampler[2]
+            hid, _, _ = ops.conv2d_nhwc((planes, b, h, w, cin), ops.conv_weight_padded(c1.weight, cin), c1.bias, 1, (1, 1),
+                                        relu=True)
+            hp, hc = ops.nhwc_planes_from([hid])
+            mask, _, _ = ops.conv2d_nhwc((hp, b, h, w, hc), c2.weight, c2.bias, 1, (0, 0))
+            return ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth, mask_nhwc=True)
         mask = self.upsampler(torch.cat([flow2, f0_map], 1))
         return self._convex(flow2, mask, is_depth=is_depth)
 

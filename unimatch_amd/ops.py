@@ -220,16 +220,17 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ convex upsampling (SURVEY 8(f) "next" row)
-    def convex_upsample(self, flow, mask, factor, is_depth=False):
-        """RAFT convex upsampling of ``flow [B,V,h,w]`` with ``mask [B,9*factor^2,h,w]`` -> ``[B,V,factor*h,factor*w]``."""
+    def convex_upsample(self, flow, mask, factor, is_depth=False, mask_nhwc=False):
+        """RAFT convex upsampling of ``flow [B,V,h,w]`` with ``mask [B,9*factor^2,h,w]`` (or NHWC ``[B*h*w, 9*factor^2]``
+        with ``mask_nhwc``) -> ``[B,V,factor*h,factor*w]``."""
         b, v, h, w = flow.shape
-        if not (flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32
-                and tuple(mask.shape) == (b, 9 * factor * factor, h, w)):
+        want = (b * h * w, 9 * factor * factor) if mask_nhwc else (b, 9 * factor * factor, h, w)
+        if not (flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32 and tuple(mask.shape) == want):
             raise ValueError(f'convex_upsample: bad shapes flow {tuple(flow.shape)} mask {tuple(mask.shape)}')
         flow, mask = flow.contiguous(), mask.contiguous()
         up = torch.empty((b, v, factor * h, factor * w), dtype=torch.float32, device=flow.device)
         code = self._launch('convex_upsample', lambda: self.lib.um_convex_upsample(
-            _ptr(flow), _ptr(mask), _ptr(up), b, v, h, w, factor, int(bool(is_depth)), _stream()))
+            _ptr(flow), _ptr(mask), _ptr(up), b, v, h, w, factor, int(bool(is_depth)), int(bool(mask_nhwc)), _stream()))
         _abi.check(code, 'um_convex_upsample')
         return up
 
@@ -287,6 +288,29 @@ class HipOps:
             stride, ph, pw, int(bool(relu)), self.WSHIFT, self.CONV_MODE, _stream()), meta)
         _abi.check(code, 'um_conv2d_fwd')
         return out, ho, wo
+
+    def nhwc_planes_from(self, pieces, pad_to=32):
+        """Operand planes of the channel concatenation of fp32 NHWC pieces ``[rows, c_i]`` (zero-padded to a multiple of
+        ``pad_to`` channels): returns ``(planes, channels)``."""
+        rows = pieces[0].shape[0]
+        c = sum(p.shape[1] for p in pieces)
+        cp = (c + pad_to - 1) // pad_to * pad_to
+        if cp != c:
+            pieces = list(pieces) + [torch.zeros((rows, cp - c), dtype=torch.float32, device=pieces[0].device)]
+        x = pieces[0].contiguous() if len(pieces) == 1 else torch.cat(list(pieces), 1)
+        planes, _ = self.nhwc_norm(x, 1, rows, normalize=False, relu=False, want_planes=True)
+        return planes, cp
+
+    def conv_weight_padded(self, weight, cin_to):
+        """``weight [cout, cin, kh, kw]`` with zero input channels appended up to ``cin_to`` (cached by the caller's
+        parameter identity through conv_weight_planes)."""
+        key, hit = self._cache_get(('padw', cin_to), (weight,))
+        if hit is None:
+            cout, cin, kh, kw = weight.shape
+            wpad = torch.zeros((cout, cin_to, kh, kw), dtype=torch.float32, device=weight.device)
+            wpad[:, :cin] = weight.detach().float()
+            hit = self._cache_put(key, (weight,), wpad)
+        return hit
 
     def stem_conv(self, image, weight, norm_mean_std=None, stats=True):
         """The encoder's 7x7/2 stem on ``um_stem_conv_fwd``: fp32 NCHW image ``[b,3,h,w]`` -> fp32 NHWC ``[b*ho*wo, cout]``.
