@@ -138,6 +138,15 @@ int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void
 int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out, int batch,
                   int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int wshift,
                   int mode, void* stream);
+/* General form.  The input planes are a column slice [a_coff, a_coff + cin) of a buffer [NS][a_rows][a_ld] whose LAST row
+ * (a_rows - 1 >= batch*hi*wi) is all zeros; the result goes to fp32 `out` [.][out_ld] at column out_coff and / or, as operand
+ * planes, to `out_planes` [NS][outp_rows][outp_ld] at column outp_coff -- so a chain of convolutions needs no fp32 round trip
+ * and channel concatenations (torch.cat of reg_refine.py:33-35, 50-53, 62-66) are column offsets.  act: 0 none, 1 ReLU,
+ * 2 sigmoid, 3 tanh (the GRU gates of reg_refine.py:55-76).  Leading dimensions / offsets: multiples of 8 (input) / 4 (output). */
+int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias, float* out,
+                 int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows, float* stats_out,
+                 int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int act,
+                 int wshift, int mode, void* stream);
 /* stats_out (optional, um_conv_stats_bytes() bytes, needs ho*wo % 128 == 0): per 128-pixel output tile the (mean, 0, sum of
  * squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
  * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */
@@ -150,6 +159,15 @@ size_t um_conv_stats_bytes(int batch, int pixels, int channels);
  * rearranged to [cout][7 ky][8 kx][4 ci] with zeros at kx = 7 and ci = 3 (n = cout, k = 224).  out: fp32 NHWC
  * [batch * ho * wo][cout], ho = (h - 1) / 2 + 1.  stats_out: as um_conv2d_fwd. */
 size_t um_stem_planes_bytes(int batch, int h, int w);
+/* General form: 7x7 / pad 3 convolution of an fp32 NCHW image with few channels (stride 2: <= 3 channels, packed 4 per pixel;
+ * stride 1: <= 8 channels, packed 8 per pixel -- the motion encoder's flow branch, unimatch/reg_refine.py:13), outputs as
+ * um_conv2d_ex.  w_planes: the weight rearranged to [cout][7 ky][8 kx][cpp] with zeros at kx = 7 and the missing channels
+ * (k = 56 cpp).  mean3 / std3 are HOST arrays. */
+size_t um_conv7_planes_bytes(int batch, int h, int w, int stride);
+int um_conv7_fwd(const float* image, int channels, int normalize, const float* mean3, const float* std3, void* image_planes,
+                 const void* w_planes, const float* bias, float* out, int out_ld, int out_coff, void* out_planes, int outp_ld,
+                 int outp_coff, long outp_rows, float* stats_out, int batch, int h, int w, int cout, int stride, int act,
+                 int wshift, void* stream);
 int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, const float* std3, void* image_planes,
                      const void* w_planes, float* out, float* stats_out, int batch, int h, int w, int cout, int wshift,
                      void* stream);
@@ -163,6 +181,14 @@ size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channels);
 int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch, int pixels,
                           int channels, float eps, int normalize, int relu, const float* conv_stats, void* workspace,
                           size_t workspace_bytes, int mode, void* stream);
+
+/* Channels-last element-wise helpers of the refinement block (SepConvGRU, unimatch/reg_refine.py:55-76); every result is
+ * written as operand planes into columns [coff, coff + channels) of a buffer [NS = 2][plane_rows][ld]:
+ *   mode 0  planes = src[rows][src_ld] (first `channels` columns)                      -- column scatter (flow, hidden state)
+ *   mode 1  planes = r * h,   r = zr[rows][2C] columns C..2C,  h = hbuf[rows][C]
+ *   mode 2  h <- (1 - z) * h + z * q  (z = zr columns 0..C, q = src), written back to hbuf and (if planes_out) as planes. */
+int um_nhwc_gate(int mode, const float* src, int src_ld, const float* zr, float* hbuf, void* planes_out, int ld, int coff,
+                 long plane_rows, long rows, int channels, void* stream);
 
 /* fp32 NCHW [batch][channels][pixels] (the output of a MIOpen convolution) -> NHWC operand planes (with the zero row)
  * and / or fp32 NHWC.  channels: multiple of 8, <= 256. */
@@ -208,6 +234,11 @@ int um_local_corr_softmax(const float* f0, const float* f1, float* out,
  * flow: [B, 2, h, w]; cost: [B, (2r+1)^2, h, w]. */
 int um_local_corr_with_flow(const float* f0, const float* f1, const float* flow, float* cost,
                             int batch, int h, int w, int channels, int radius, void* stream);
+/* Same cost volume written channels-last as the operand planes of the motion encoder's 1x1 convolution
+ * (unimatch/reg_refine.py:11,20): planes_out [2][plane_rows][ld], pixel row = (2r+1)^2 taps then zeros up to ld; the fp32
+ * [B, taps, h, w] volume is never formed ("K4 fused into convc1"). */
+int um_local_corr_with_flow_planes(const float* f0, const float* f1, const float* flow, void* planes_out, int ld, long plane_rows,
+                                   int batch, int h, int w, int channels, int radius, void* stream);
 
 /* (2r+1)^2 local self-attention propagation with zero-padded keys/values (out-of-image neighbours
  * have logit 0, value 0 and take part in the softmax).

@@ -418,6 +418,43 @@ def test_conv2d_nhwc_matches_fp64(ops, case):
     assert err(got, want)[0] < 3e-6 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('fd,hw', [(2, (16, 24)), (1, (12, 20))])
+def test_nhwc_update_block_matches_module(ops, fd, hw):
+    """The channels-last refinement block (refine_nhwc.NhwcUpdateBlock: K4 -> planes, concat-free convolution chain, fused
+    gates) against the stock BasicUpdateBlock module evaluated in fp64 on the same weights and inputs."""
+    from unimatch_amd.refine import BasicUpdateBlock
+    from unimatch_amd.refine_nhwc import NhwcUpdateBlock
+    torch.manual_seed(5)
+    b, (h, w) = 2, hw
+    block = BasicUpdateBlock(corr_channels=81, downsample_factor=4, flow_dim=fd)
+    proj = torch.nn.Conv2d(128, 256, 1)
+    f0 = rnd(101, b, h * w, 128)
+    ori0, ori1 = rnd(102, b, h * w, 128), rnd(103, b, h * w, 128)
+    flow = rnd(104, b, fd, h, w, scale=2.0)
+    disp = torch.cat([-flow, torch.zeros_like(flow)], 1) if fd == 1 else flow
+    # fp64 reference with the oracle's cost volume
+    blk64, proj64 = BasicUpdateBlock(81, downsample_factor=4, flow_dim=fd).double(), torch.nn.Conv2d(128, 256, 1).double()
+    blk64.load_state_dict({k: v.double() for k, v in block.state_dict().items()})
+    proj64.load_state_dict({k: v.double() for k, v in proj.state_dict().items()})
+    with torch.no_grad():
+        fmap = f0.double().transpose(1, 2).reshape(b, 128, h, w)
+        p64 = proj64(fmap)
+        net0, inp = torch.tanh(p64[:, :128]), torch.relu(p64[:, 128:])
+        corr = hp.local_corr_with_flow(ori0.double().transpose(1, 2).reshape(b, 128, h, w),
+                                       ori1.double().transpose(1, 2).reshape(b, 128, h, w), disp.double(), 4)
+        _, mask64, delta64 = blk64(net0, inp, corr, flow.double())
+    block, proj = block.to(DEV), proj.to(DEV)
+    upd = NhwcUpdateBlock(ops, block, proj)
+    upd.begin(f0.to(DEV), b, h, w)
+    mask, delta = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert err(delta, delta64)[0] < 2e-5 * max(1.0, delta64.abs().max().item())
+    got_mask = mask.view(b, h, w, -1).permute(0, 3, 1, 2)
+    assert err(got_mask, mask64)[0] < 2e-5 * max(1.0, mask64.abs().max().item())
+    # a second iteration must not depend on state left by the first (the hidden state restarts from net0)
+    mask2, delta2 = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert torch.equal(delta2, delta) and torch.equal(mask2, mask)
+
+
 @pytest.mark.parametrize('bhw,normalize', [((2, 64, 96), True), ((1, 37, 51), False), ((3, 16, 32), True)])
 def test_stem_conv_matches_fp64(ops, bhw, normalize):
     """um_stem_conv_fwd: the 7x7 / stride 2 / pad 3 stem through the packed NHWC-4 image planes against torch conv2d in

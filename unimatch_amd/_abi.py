@@ -28,8 +28,16 @@ SIGNATURES = {
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),
     'um_ffn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
     'um_conv2d_fwd': (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_void_p]),
+    'um_conv2d_ex': (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p,
+                              _c_int, _c_int, ctypes.c_long, _c_void_p] + [_c_int] * 13 + [_c_void_p]),
+    'um_nhwc_gate': (_c_int, [_c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_long, ctypes.c_long,
+                              _c_int, _c_void_p]),
+    'um_local_corr_with_flow_planes': (_c_int, [_c_void_p] * 4 + [_c_int, ctypes.c_long] + [_c_int] * 5 + [_c_void_p]),
     'um_conv_stats_bytes': (_c_size_t, [_c_int] * 3),
     'um_stem_planes_bytes': (_c_size_t, [_c_int] * 3),
+    'um_conv7_planes_bytes': (_c_size_t, [_c_int] * 4),
+    'um_conv7_fwd': (_c_int, [_c_void_p, _c_int, _c_int] + [_c_void_p] * 6 + [_c_int, _c_int, _c_void_p, _c_int, _c_int, ctypes.c_long,
+                              _c_void_p] + [_c_int] * 7 + [_c_void_p]),
     'um_stem_conv_fwd': (_c_int, [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
     'um_nhwc_norm_workspace_bytes': (_c_size_t, [_c_int] * 3),
     'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_void_p,

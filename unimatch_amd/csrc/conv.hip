@@ -28,12 +28,15 @@ struct ConvArgs {
     const unsigned short* wp;     // [NS][Cout][taps * Cin]
     long w_plane_stride;
     const float* bias;            // [Cout] or null
-    float* out;                   // [M][Cout]
+    float* out;                   // optional fp32 [M][out_ld], written at column offset out_coff
+    unsigned short* outp;         // optional operand planes [NS][...][outp_ld] at column offset outp_coff (the next
+    long outp_plane_stride;       //   convolution's input: no fp32 round trip, channel concatenation by offset)
+    int out_ld, out_coff, outp_ld, outp_coff;
+    int act;                      // 0 none, 1 ReLU, 2 sigmoid, 3 tanh
     float* stats;                 // optional [M / 128][3][Cout]: per 128-pixel tile (mean, 0, sum of squared deviations)
     int B, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad_h, pad_w;
     int M;                        // B * Ho * Wo
-    int relu;
     float out_scale;              // 2^-wshift
 };
 
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] * a.out_scale;
                 if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
-                if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
+                else if (a.act == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
+                else if (a.act == 3) v[i] = tanhf(v[i]);
             }
             const int c = 8 * nt + 2 * g + half;                 // 16-byte chunk index inside the row
             *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
@@ -242,8 +247,19 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         const int idx = it * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
         const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-        if (row0 + r < a.M && n0 + 4 * c < a.Cout)
-            *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.Cout + n0 + 4 * c) = d;
+        if (row0 + r < a.M && n0 + 4 * c < a.Cout) {
+            if (a.out) *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.out_ld + a.out_coff + n0 + 4 * c) = d;
+            if (a.outp) {
+                unsigned short* dst = a.outp + (long)(row0 + r) * a.outp_ld + a.outp_coff + n0 + 4 * c;
+                const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
+                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                if (NS == 2) {
+                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
+                    *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
+                        u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                }
+            }
+        }
     }
 }
 
@@ -261,39 +277,52 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
     return hipGetLastError();
 }
 
-extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,
-                             int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w,
-                             int relu, int wshift, int mode, void* stream_) {
-    if (!a_planes || !w_planes || !out || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 || cout <= 0 ||
-        cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) || wshift < 0 ||
-        wshift > 14) {
-        um_set_error("um_conv2d_fwd: bad argument (batch=%d hi=%d wi=%d cin=%d cout=%d k=%dx%d stride=%d pad=%d,%d; cin must be a "
-                     "multiple of 32, cout of 4)", batch, hi, wi, cin, cout, kh, kw, stride, pad_h, pad_w);
+extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
+                            float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
+                            float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
+                            int pad_h, int pad_w, int act, int wshift, int mode, void* stream_) {
+    if (!a_planes || !w_planes || (!out && !out_planes) || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 ||
+        cout <= 0 || cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) ||
+        wshift < 0 || wshift > 14 || act < 0 || act > 3) {
+        um_set_error("um_conv2d: bad argument (batch=%d hi=%d wi=%d cin=%d cout=%d k=%dx%d stride=%d pad=%d,%d act=%d; cin must "
+                     "be a multiple of 32, cout of 4)", batch, hi, wi, cin, cout, kh, kw, stride, pad_h, pad_w, act);
         return -1;
     }
     const int ho = (hi + 2 * pad_h - kh) / stride + 1, wo = (wi + 2 * pad_w - kw) / stride + 1;
     if (ho <= 0 || wo <= 0) {
-        um_set_error("um_conv2d_fwd: empty output (%d x %d)", ho, wo);
+        um_set_error("um_conv2d: empty output (%d x %d)", ho, wo);
         return -1;
     }
     const long rows_in = (long)batch * hi * wi, m = (long)batch * ho * wo;
-    if (stats_out && ((long)ho * wo) % 128 != 0) {
-        um_set_error("um_conv2d_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+    if (a_ld < a_coff + cin || a_ld % 8 != 0 || a_coff % 8 != 0 || a_rows < rows_in + 1 ||
+        (out && (out_ld < out_coff + cout || out_ld % 4 != 0 || out_coff % 4 != 0)) ||
+        (out_planes && (outp_ld < outp_coff + cout || outp_ld % 4 != 0 || outp_coff % 4 != 0 || outp_rows < m))) {
+        um_set_error("um_conv2d: inconsistent leading dimensions / offsets / row counts");
         return -1;
     }
-    if ((rows_in + 1) * cin * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
-        um_set_error("um_conv2d_fwd: operand planes beyond 4 GiB are not addressable by this kernel");
+    if (stats_out && (((long)ho * wo) % 128 != 0 || !out)) {
+        um_set_error("um_conv2d: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+        return -1;
+    }
+    if (a_rows * a_ld * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
+        um_set_error("um_conv2d: operand planes beyond 4 GiB are not addressable by this kernel");
         return -4;
     }
     ConvArgs a;
-    a.ap = (const unsigned short*)a_planes;
-    a.a_plane_stride = (rows_in + 1) * cin;
-    a.row_stride = (unsigned)cin * 2;
-    a.zero_row = (unsigned)rows_in;
+    a.ap = (const unsigned short*)a_planes + a_coff;
+    a.a_plane_stride = a_rows * a_ld;
+    a.row_stride = (unsigned)a_ld * 2;
+    a.zero_row = (unsigned)(a_rows - 1);
     a.wp = (const unsigned short*)w_planes;
     a.w_plane_stride = (long)cout * kh * kw * cin;
     a.bias = bias;
     a.out = out;
+    a.out_ld = out_ld;
+    a.out_coff = out_coff;
+    a.outp = (unsigned short*)out_planes;
+    a.outp_ld = outp_ld;
+    a.outp_coff = outp_coff;
+    a.outp_plane_stride = outp_rows * outp_ld;
     a.stats = stats_out;
     a.B = batch;
     a.Hi = hi;
@@ -308,7 +337,7 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
     a.pad_h = pad_h;
     a.pad_w = pad_w;
     a.M = (int)m;
-    a.relu = relu;
+    a.act = act;
     a.out_scale = ldexpf(1.f, -wshift);
     hipError_t e;
     // widest output tile that does not waste more than a third of its columns
@@ -317,21 +346,31 @@ extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const f
     else if (cout <= 64 || cout % 64 == 0) e = launch_conv<2>(a, mode, (hipStream_t)stream_);
     else e = launch_conv<4>(a, mode, (hipStream_t)stream_);
     if (e != hipSuccess) {
-        um_set_error("um_conv2d_fwd: launch failed: %s", hipGetErrorString(e));
+        um_set_error("um_conv2d: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
     return 0;
 }
 
-// ---- the 7x7 / stride-2 stem (unimatch/backbone.py:49, 3 -> 64 channels) on the same kernel ------------------------------
-// The image is packed once into zero-bordered NHWC-4 planes [NS][B][H + 6][Wp][4] (channel 3 = 0, Wp = W + 6 rounded up to
-// even).  For output pixel (y, x) and kernel row ky the 7 taps x 3 channels are then 32 CONTIGUOUS elements starting at
-// packed pixel (2y + ky, 2x): pixels 2x .. 2x+7 x 4 channels, where the 8th pixel and the 4th channel meet zero weights.
-// So the stem is a "7 x 1 convolution with 32 input channels" whose rows advance by one packed pixel (8 bytes): K = 224
-// instead of 147, no im2col, no border logic, 16-byte aligned LDS-DMA.
-__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, unsigned short* planes, long plane_stride, int B,
-                                                        int H, int W, int Hp, int Wp, int normalize, float m0, float m1,
-                                                        float m2, float s0, float s1, float s2) {
+extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,
+                             int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w,
+                             int relu, int wshift, int mode, void* stream_) {
+    const long rows_in = (long)batch * hi * wi;
+    return um_conv2d_ex(a_planes, cin, 0, rows_in + 1, w_planes, bias, out, cout, 0, nullptr, 0, 0, 0, stats_out, batch, hi, wi,
+                        cin, cout, kh, kw, stride, pad_h, pad_w, relu ? 1 : 0, wshift, mode, stream_);
+}
+
+// ---- 7x7 convolutions with very few input channels on the same kernel ----------------------------------------------------
+// (the encoder stem, unimatch/backbone.py:49: 3 -> 64, stride 2; the motion encoder's flow branch, reg_refine.py:13: 1|2 -> 128,
+// stride 1).  The image is packed once into zero-bordered NHWC planes with CPP channels per pixel (4 for stride 2, 8 for
+// stride 1; missing channels = 0), [NS][B][H + 6][Wp][CPP].  For output pixel (y, x) and kernel row ky the 7 taps x C
+// channels are then 8 CPP CONTIGUOUS elements starting at packed pixel (s y + ky, s x): pixels s x .. s x + 7, where the 8th
+// pixel and the missing channels meet zero weights.  So the layer is a "7 x 1 convolution with 8 CPP input channels" whose
+// rows advance by one packed pixel: no im2col, no border logic, 16-byte aligned LDS-DMA (K = 224 / 448 instead of 49 C).
+template <int CPP>
+__global__ __launch_bounds__(256) void pack7_kernel(const float* img, unsigned short* planes, long plane_stride, int B, int C,
+                                                    int H, int W, int Hp, int Wp, int normalize, float m0, float m1, float m2,
+                                                    float s0, float s1, float s2) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * Hp * Wp;
     if (idx >= total) return;
@@ -339,89 +378,126 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, unsign
     const long t = idx / Wp;
     const int yp = (int)(t % Hp), b = (int)(t / Hp);
     const int y = yp - 3, x = xp - 3;
-    float v[3] = {0.f, 0.f, 0.f};
+    float v[CPP];
+#pragma unroll
+    for (int c = 0; c < CPP; ++c) v[c] = 0.f;
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
         const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float p = img[(((long)b * 3 + c) * H + y) * W + x];
-            if (normalize) p = (p / 255.0f - mean[c]) / sd[c];        // the reference's operation order (unimatch.py:122-124)
-            v[c] = p;
+        for (int c = 0; c < CPP; ++c) {
+            if (c < C) {
+                float p = img[(((long)b * C + c) * H + y) * W + x];
+                if (normalize && c < 3) p = (p / 255.0f - mean[c]) / sd[c];    // the reference's operation order (unimatch.py:122-124)
+                v[c] = p;
+            }
         }
     }
-    const unsigned h0 = Fp16::pack2(v[0], v[1]), h1 = Fp16::pack2(v[2], 0.f);
-    *reinterpret_cast<u32x2*>(planes + idx * 4) = u32x2{h0, h1};
-    const f32x2 u0 = Fp16::unpack2(h0), u1 = Fp16::unpack2(h1);
-    *reinterpret_cast<u32x2*>(planes + plane_stride + idx * 4) =
-        u32x2{Fp16::pack2(v[0] - u0[0], v[1] - u0[1]), Fp16::pack2(v[2] - u1[0], 0.f)};
+#pragma unroll
+    for (int c = 0; c < CPP; c += 4) {
+        const unsigned h0 = Fp16::pack2(v[c], v[c + 1]), h1 = Fp16::pack2(v[c + 2], v[c + 3]);
+        *reinterpret_cast<u32x2*>(planes + idx * CPP + c) = u32x2{h0, h1};
+        const f32x2 u0 = Fp16::unpack2(h0), u1 = Fp16::unpack2(h1);
+        *reinterpret_cast<u32x2*>(planes + plane_stride + idx * CPP + c) =
+            u32x2{Fp16::pack2(v[c] - u0[0], v[c + 1] - u0[1]), Fp16::pack2(v[c + 2] - u1[0], v[c + 3] - u1[1])};
+    }
 }
 
-extern "C" size_t um_stem_planes_bytes(int batch, int h, int w) {
-    if (batch <= 0 || h <= 0 || w <= 0) return 0;
-    const long hp = h + 6, wp = (w + 6 + 1) & ~1L;
-    return (size_t)(2 * ((long)batch * hp * wp + 8) * 4 * 2);    // two fp16 planes, 8 pixels of slack
+static int conv7_wp(int w) { return (w + 8 + 1) & ~1; }
+
+extern "C" size_t um_conv7_planes_bytes(int batch, int h, int w, int stride) {
+    if (batch <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return 0;
+    const long cpp = stride == 2 ? 4 : 8;
+    return (size_t)(2 * ((long)batch * (h + 6) * conv7_wp(w) + 8) * cpp * 2);    // two fp16 planes, 8 pixels of slack
 }
 
-extern "C" int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, const float* std3, void* image_planes,
-                                const void* w_planes, float* out, float* stats_out, int batch, int h, int w, int cout,
-                                int wshift, void* stream_) {
+extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, const float* mean3, const float* std3,
+                            void* image_planes, const void* w_planes, const float* bias, float* out, int out_ld, int out_coff,
+                            void* out_planes, int outp_ld, int outp_coff, long outp_rows, float* stats_out, int batch, int h,
+                            int w, int cout, int stride, int act, int wshift, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!image || !image_planes || !w_planes || !out || batch <= 0 || h < 7 || w < 7 || cout <= 0 || cout % 4 != 0 || wshift < 0 ||
-        wshift > 14 || (normalize && (!mean3 || !std3))) {
-        um_set_error("um_stem_conv_fwd: bad argument (batch=%d h=%d w=%d cout=%d)", batch, h, w, cout);
+    const int cpp = stride == 2 ? 4 : 8;
+    if (!image || !image_planes || !w_planes || (!out && !out_planes) || batch <= 0 || h < 7 || w < 7 || cout <= 0 || cout % 4 != 0 ||
+        wshift < 0 || wshift > 14 || (stride != 1 && stride != 2) || channels <= 0 || channels > (stride == 2 ? 3 : 8) ||
+        (normalize && (!mean3 || !std3)) || act < 0 || act > 3) {
+        um_set_error("um_conv7_fwd: bad argument (batch=%d channels=%d h=%d w=%d cout=%d stride=%d)", batch, channels, h, w, cout, stride);
         return -1;
     }
-    const int hp = h + 6, wp = (w + 6 + 1) & ~1;
-    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;       // (h + 2*3 - 7) / 2 + 1
-    const long rows = (long)batch * hp * wp;
-    if (stats_out && ((long)ho * wo) % 128 != 0) {
-        um_set_error("um_stem_conv_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+    const int hp = h + 6, wp = conv7_wp(w);
+    const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;       // (h + 2*3 - 7) / stride + 1
+    const long rows = (long)batch * hp * wp, m = (long)batch * ho * wo;
+    if ((out && (out_ld < out_coff + cout || out_ld % 4 != 0 || out_coff % 4 != 0)) ||
+        (out_planes && (outp_ld < outp_coff + cout || outp_ld % 4 != 0 || outp_coff % 4 != 0 || outp_rows < m))) {
+        um_set_error("um_conv7_fwd: inconsistent leading dimensions / offsets / row counts");
         return -1;
     }
-    if ((rows + 8) * 8 >= (1L << 32) || (long)batch * ho * wo >= (1L << 31)) {
-        um_set_error("um_stem_conv_fwd: image batch beyond the 32-bit addressing of this kernel");
+    if (stats_out && (((long)ho * wo) % 128 != 0 || !out)) {
+        um_set_error("um_conv7_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+        return -1;
+    }
+    if ((rows + 8) * cpp * 2 >= (1L << 32) || m >= (1L << 31)) {
+        um_set_error("um_conv7_fwd: image batch beyond the 32-bit addressing of this kernel");
         return -4;
     }
-    const long plane_stride = (rows + 8) * 4;
+    const long plane_stride = (rows + 8) * cpp;
     {
         ScopedKernelTimer timer(UM_K_CONV, stream);
-        hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, image,
-                           (unsigned short*)image_planes, plane_stride, batch, h, w, hp, wp, normalize,
-                           normalize ? mean3[0] : 0.f, normalize ? mean3[1] : 0.f, normalize ? mean3[2] : 0.f,
-                           normalize ? std3[0] : 1.f, normalize ? std3[1] : 1.f, normalize ? std3[2] : 1.f);
+        const float mm[3] = {normalize ? mean3[0] : 0.f, normalize ? mean3[1] : 0.f, normalize ? mean3[2] : 0.f};
+        const float ss[3] = {normalize ? std3[0] : 1.f, normalize ? std3[1] : 1.f, normalize ? std3[2] : 1.f};
+        const dim3 grid((unsigned)((rows + 255) / 256));
+        if (cpp == 4)
+            hipLaunchKernelGGL((pack7_kernel<4>), grid, dim3(256), 0, stream, image, (unsigned short*)image_planes, plane_stride,
+                               batch, channels, h, w, hp, wp, normalize, mm[0], mm[1], mm[2], ss[0], ss[1], ss[2]);
+        else
+            hipLaunchKernelGGL((pack7_kernel<8>), grid, dim3(256), 0, stream, image, (unsigned short*)image_planes, plane_stride,
+                               batch, channels, h, w, hp, wp, normalize, mm[0], mm[1], mm[2], ss[0], ss[1], ss[2]);
     }
     ConvArgs a;
     a.ap = (const unsigned short*)image_planes;
     a.a_plane_stride = plane_stride;
-    a.row_stride = 8;                                             // one packed pixel
+    a.row_stride = (unsigned)cpp * 2;                             // one packed pixel
     a.zero_row = 0;                                               // never used: every tap is inside the padded image
     a.wp = (const unsigned short*)w_planes;
-    a.w_plane_stride = (long)cout * 224;
-    a.bias = nullptr;
+    a.w_plane_stride = (long)cout * 7 * 8 * cpp;
+    a.bias = bias;
     a.out = out;
+    a.out_ld = out_ld;
+    a.out_coff = out_coff;
+    a.outp = (unsigned short*)out_planes;
+    a.outp_ld = outp_ld;
+    a.outp_coff = outp_coff;
+    a.outp_plane_stride = outp_rows * outp_ld;
     a.stats = stats_out;
     a.B = batch;
     a.Hi = hp;
     a.Wi = wp;
-    a.Cin = 32;
+    a.Cin = 8 * cpp;
     a.Ho = ho;
     a.Wo = wo;
     a.Cout = cout;
     a.KH = 7;
     a.KW = 1;
-    a.stride = 2;
+    a.stride = stride;
     a.pad_h = 0;
     a.pad_w = 0;
-    a.M = (int)((long)batch * ho * wo);
-    a.relu = 0;
+    a.M = (int)m;
+    a.act = act;
     a.out_scale = ldexpf(1.f, -wshift);
     hipError_t e;
-    if (cout % 128 == 0) e = launch_conv<4>(a, 0, stream);
+    if (cout % 128 == 0 || cout > 192) e = launch_conv<4>(a, 0, stream);
     else if (cout % 96 == 0) e = launch_conv<3>(a, 0, stream);
     else e = launch_conv<2>(a, 0, stream);
     if (e != hipSuccess) {
-        um_set_error("um_stem_conv_fwd: launch failed: %s", hipGetErrorString(e));
+        um_set_error("um_conv7_fwd: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
     return 0;
+}
+
+extern "C" size_t um_stem_planes_bytes(int batch, int h, int w) { return um_conv7_planes_bytes(batch, h, w, 2); }
+
+extern "C" int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, const float* std3, void* image_planes,
+                                const void* w_planes, float* out, float* stats_out, int batch, int h, int w, int cout,
+                                int wshift, void* stream_) {
+    return um_conv7_fwd(image, 3, normalize, mean3, std3, image_planes, w_planes, nullptr, out, cout, 0, nullptr, 0, 0, 0, stats_out,
+                        batch, h, w, cout, 2, 0, wshift, stream_);
 }

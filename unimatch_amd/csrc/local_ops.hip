@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
                                                                    const float* __restrict__ f1,
                                                                    const float* __restrict__ flow,
                                                                    float* __restrict__ cost, int batch, int h, int w,
-                                                                   int radius) {
+                                                                   int radius, unsigned short* __restrict__ planes,
+                                                                   long plane_stride, int ld) {
     __shared__ float dots_s[4][K4_MAX_DOTS + 4];
     __shared__ float tile_s[4][K4_MAX_TAPS][K4_PIX + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -192,6 +193,22 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (planes) {
+            // channels-last operand planes for um_conv2d_ex (the motion encoder's 1x1 convolution reads them directly: the
+            // [B, taps, h, w] fp32 volume never exists): pixel row = ld channels, taps first, zeros up to ld
+            const int pairs = ld >> 1;
+            for (int idx = lane; idx < pairs * K4_PIX; idx += 64) {
+                const int j = idx / pairs, c = (idx - j * pairs) * 2;
+                const long pid = p0 + j;
+                if (pid < total) {
+                    const float v0 = c < ntaps ? tile_s[wave][c][j] : 0.f, v1 = c + 1 < ntaps ? tile_s[wave][c + 1][j] : 0.f;
+                    const unsigned hh = Fp16::pack2(v0, v1);
+                    const f32x2 u = Fp16::unpack2(hh);
+                    *reinterpret_cast<unsigned*>(planes + pid * ld + c) = hh;
+                    *reinterpret_cast<unsigned*>(planes + plane_stride + pid * ld + c) = Fp16::pack2(v0 - u[0], v1 - u[1]);
+                }
+            }
+        } else
         // write the [taps][16] tile: 16 consecutive pixels of one tap are contiguous in the volume
         for (int idx = lane; idx < ntaps * K4_PIX; idx += 64) {
             const int k = idx / K4_PIX, j = idx - k * K4_PIX;
@@ -423,7 +440,22 @@ extern "C" int um_local_corr_with_flow(const float* f0, const float* f1, const f
     const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
     ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
     hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0,
-                       (hipStream_t)stream, f0, f1, flow, cost, batch, h, w, radius);
+                       (hipStream_t)stream, f0, f1, flow, cost, batch, h, w, radius, (unsigned short*)nullptr, 0L, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int um_local_corr_with_flow_planes(const float* f0, const float* f1, const float* flow, void* planes_out, int ld,
+                                              long plane_rows, int batch, int h, int w, int channels, int radius, void* stream) {
+    if (int e = local_check(f0, f1, planes_out, batch, h, w, channels)) return e;
+    const int ntaps = (2 * radius + 1) * (2 * radius + 1);
+    if (!flow || radius < 1 || ntaps > K4_MAX_TAPS || ld < ntaps || ld % 8 != 0 || plane_rows < (long)batch * h * w + 1) {
+        um_set_error("um_local_corr_with_flow_planes: bad argument (radius=%d ld=%d rows=%ld)", radius, ld, plane_rows);
+        return -1;
+    }
+    const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
+    ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
+    hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0, (hipStream_t)stream, f0, f1,
+                       flow, (float*)nullptr, batch, h, w, radius, (unsigned short*)planes_out, plane_rows * ld, ld);
     return (int)hipGetLastError();
 }
 

@@ -210,6 +210,51 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, unsig
     }
 }
 
+// ---- small channels-last helpers of the refinement block (SepConvGRU gate arithmetic, reg_refine.py:55-76) ------------------
+// One thread = 4 channels of one pixel.  mode 0: planes[coff + c] = src[c]                      (column scatter)
+//                                         mode 1: planes[coff + c] = zr[C + c] * h[c]             (r * h)
+//                                         mode 2: h[c] = (1 - zr[c]) * h[c] + zr[c] * q[c]; planes[coff + c] = h[c]
+__global__ __launch_bounds__(256) void nhwc_gate_kernel(int mode, const float* src, int src_ld, const float* zr, float* hbuf,
+                                                        unsigned short* planes, long plane_stride, int ld, int coff, long rows,
+                                                        int C) {
+    const int c4n = (C + 3) >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * c4n) return;
+    const long row = idx / c4n;
+    const int c = (int)(idx - row * c4n) * 4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = c + i;
+        float x = 0.f;
+        if (ci < C) {
+            if (mode == 0) x = src[row * src_ld + ci];
+            else if (mode == 1) x = zr[row * (2 * C) + C + ci] * hbuf[row * C + ci];
+            else {
+                const float z = zr[row * (2 * C) + ci];
+                x = (1.0f - z) * hbuf[row * C + ci] + z * src[row * src_ld + ci];
+                hbuf[row * C + ci] = x;
+            }
+        }
+        v[i] = x;
+    }
+    if (!planes) return;
+    const unsigned h0 = Fp16::pack2(v[0], v[1]), h1 = Fp16::pack2(v[2], v[3]);
+    const f32x2 u0 = Fp16::unpack2(h0), u1 = Fp16::unpack2(h1);
+    const unsigned l0 = Fp16::pack2(v[0] - u0[0], v[1] - u0[1]), l1 = Fp16::pack2(v[2] - u1[0], v[3] - u1[1]);
+    unsigned short* d = planes + row * ld + coff + c;
+    if (c + 4 <= C) {
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + plane_stride) = u32x2{l0, l1};
+    } else {                                                      // ragged tail (C = 1, 2, 3 ...): element stores
+        const unsigned hh[2] = {h0, h1}, ll[2] = {l0, l1};
+        for (int i = 0; c + i < C; ++i) {
+            d[i] = (unsigned short)(hh[i >> 1] >> (16 * (i & 1)));
+            d[plane_stride + i] = (unsigned short)(ll[i >> 1] >> (16 * (i & 1)));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
 
@@ -296,6 +341,28 @@ extern "C" int um_nchw_to_nhwc(const float* x, void* planes_out, float* f32_out,
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         um_set_error("um_nchw_to_nhwc: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int um_nhwc_gate(int mode, const float* src, int src_ld, const float* zr, float* hbuf, void* planes_out, int ld, int coff,
+                            long plane_rows, long rows, int channels, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool ok = rows > 0 && channels > 0 && mode >= 0 && mode <= 2 && (mode == 1 || src) && (mode == 0 || (zr && hbuf)) &&
+                    (mode == 2 || planes_out) &&
+                    (!planes_out || (ld >= coff + channels && plane_rows >= rows && (channels % 4 != 0 || coff % 4 == 0)));
+    if (!ok) {
+        um_set_error("um_nhwc_gate: bad argument (mode=%d rows=%ld channels=%d ld=%d coff=%d)", mode, rows, channels, ld, coff);
+        return -1;
+    }
+    const long total = rows * ((channels + 3) / 4);
+    ScopedKernelTimer timer(UM_K_INSTANCE_NORM, stream);
+    hipLaunchKernelGGL(nhwc_gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mode, src, src_ld, zr, hbuf,
+                       (unsigned short*)planes_out, plane_rows * ld, ld, coff, rows, channels);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        um_set_error("um_nhwc_gate: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
     return 0;

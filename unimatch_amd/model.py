@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from .encoder import CNNEncoder
 from .refine import BasicUpdateBlock, convex_upsample
+from .refine_nhwc import NhwcUpdateBlock
 
 _IMAGENET_MEAN = (0.485, 0.456, 0.406)
 _IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -436,8 +437,13 @@ class UniMatch(nn.Module):
                     continue
                 assert num_reg_refine > 0
                 pose_r = pose
-                proj = self.refine_proj(f0_map)                 # same every iteration (unimatch.py:315-320)
-                net0, inp = torch.tanh(proj[:, :128]), torch.relu(proj[:, 128:])
+                nhwc = None                                     # channels-last refinement block on the library's convolutions
+                if getattr(ops, 'fused_conv', False) and tok0.is_cuda and task in ('flow', 'stereo'):
+                    nhwc = NhwcUpdateBlock(ops, self.refine, self.refine_proj)
+                    nhwc.begin(tok0, tok0.shape[0], h, w)
+                else:
+                    proj = self.refine_proj(f0_map)             # same every iteration (unimatch.py:315-320)
+                    net0, inp = torch.tanh(proj[:, :128]), torch.relu(proj[:, 128:])
                 for it in range(num_reg_refine):
                     if task == 'stereo':
                         disp = torch.cat([-flow, torch.zeros_like(flow)], 1)
@@ -449,8 +455,11 @@ class UniMatch(nn.Module):
                         disp = _rigid_flow(1. / flow.squeeze(1), k_cur, pose_r)
                     else:
                         disp = flow
-                    corr = ops.local_corr_with_flow(ori0, ori1, disp.contiguous(), h, w, 4)
-                    _, up_mask, delta = self.refine(net0, inp, corr, flow)
+                    if nhwc is not None:
+                        up_mask, delta = nhwc.iterate(ori0, ori1, disp.contiguous(), flow, it == num_reg_refine - 1)
+                    else:
+                        corr = ops.local_corr_with_flow(ori0, ori1, disp.contiguous(), h, w, 4)
+                        _, up_mask, delta = self.refine(net0, inp, corr, flow)
                     if task == 'depth':
                         flow = (flow - delta).clamp(min=min_depth, max=max_depth)
                     else:
@@ -462,6 +471,8 @@ class UniMatch(nn.Module):
                             pad = torch.cat([flow, torch.zeros_like(flow)], 1)
                             pred = self._upsample(pad, f0_map, is_depth=True).clamp(
                                 min=min_depth, max=max_depth)[:, :1]
+                        elif nhwc is not None:
+                            pred = ops.convex_upsample(flow, up_mask, self.upsample_factor, False, mask_nhwc=True)
                         else:
                             pred = self._convex(flow, up_mask)
             if task == 'stereo':

@@ -312,6 +312,84 @@ class HipOps:
             hit = self._cache_put(key, (weight,), wpad)
         return hit
 
+    # ---- building blocks of the channels-last refinement block (unimatch_amd/refine_nhwc.py) ---------------------------------
+    def planes_buffer(self, rows, ld):
+        """Zeroed operand-plane buffer ``[2][rows + 1][ld]`` (fp16 hi | lo); row ``rows`` is the zero padding row."""
+        return torch.zeros(2 * (rows + 1) * ld * 2, dtype=torch.uint8, device='cuda')
+
+    def conv_weight_planes_from(self, weight):
+        """Uncached: planes of ``weight [cout, cin, kh, kw]`` permuted to ``[cout, kh*kw*cin]`` -> ``(planes, cout, cin, kh, kw)``."""
+        cout, cin, kh, kw = weight.shape
+        w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous()
+        planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, 0), dtype=torch.uint8, device=w2.device)
+        _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, 0, _stream()),
+                   'um_weight_planes')
+        return planes, cout, cin, kh, kw
+
+    def conv_ex(self, src, geom, wb, ksize, stride, pad, act, out=None, outp=None):
+        """``um_conv2d_ex``.  ``src = (planes_buffer, ld, coff, cin)``, ``geom = (b, h, w)``, ``wb = ((w_planes, cout, cin, kh,
+        kw), bias)``, ``out = (fp32 tensor, ld, coff)``, ``outp = (planes_buffer, ld, coff)``; act 0/1/2/3 = none/ReLU/sigmoid/tanh."""
+        buf, a_ld, a_coff, cin = src
+        b, h, w = geom
+        (wp, cout, wcin, kh, kw), bias = wb
+        if wcin != cin or (kh, kw) != tuple(ksize):
+            raise ValueError(f'conv_ex: weight is {cout}x{wcin}x{kh}x{kw}, call wants cin={cin} k={ksize}')
+        a_rows = buf.numel() // (4 * a_ld)
+        ho, wo = (h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1
+        o_t, o_ld, o_coff = out if out is not None else (None, 0, 0)
+        p_t, p_ld, p_coff = outp if outp is not None else (None, 0, 0)
+        p_rows = p_t.numel() // (4 * p_ld) if p_t is not None else 0
+        code = self._launch('conv', lambda: self.lib.um_conv2d_ex(
+            _ptr(buf), a_ld, a_coff, a_rows, _ptr(wp), _ptr(bias) if bias is not None else None,
+            _ptr(o_t) if o_t is not None else None, o_ld, o_coff, _ptr(p_t) if p_t is not None else None, p_ld, p_coff, p_rows,
+            None, b, h, w, cin, cout, kh, kw, stride, pad[0], pad[1], act, self.WSHIFT, 0, _stream()),
+            {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin})
+        _abi.check(code, 'um_conv2d_ex')
+
+    def conv7(self, image, weight, bias, stride, act, out=None, outp=None):
+        """7x7 / pad 3 convolution of an fp32 NCHW image with few channels (``um_conv7_fwd``), outputs as :meth:`conv_ex`."""
+        b, c, h, w = image.shape
+        cout = weight.shape[0]
+        cpp = 4 if stride == 2 else 8
+        key, hit = self._cache_get(('conv7', stride), (weight,))
+        if hit is None:
+            wr = torch.zeros((cout, 7, 8, cpp), dtype=torch.float32, device=weight.device)
+            wr[:, :, :7, :c] = weight.detach().float().permute(0, 2, 3, 1)
+            wr = wr.reshape(cout, 56 * cpp).contiguous()
+            wp = torch.empty(self.lib.um_planes_bytes(cout, 56 * cpp, 0), dtype=torch.uint8, device=weight.device)
+            _abi.check(self.lib.um_weight_planes(_ptr(wr), _ptr(wp), cout, 56 * cpp, self.WSHIFT, 0, _stream()), 'um_weight_planes')
+            hit = self._cache_put(key, (weight,), wp)
+        scratch = torch.empty(self.lib.um_conv7_planes_bytes(b, h, w, stride), dtype=torch.uint8, device=image.device)
+        o_t, o_ld, o_coff = out if out is not None else (None, 0, 0)
+        p_t, p_ld, p_coff = outp if outp is not None else (None, 0, 0)
+        p_rows = p_t.numel() // (4 * p_ld) if p_t is not None else 0
+        image = image.contiguous()
+        code = self._launch('conv', lambda: self.lib.um_conv7_fwd(
+            _ptr(image), c, 0, None, None, _ptr(scratch), _ptr(hit), _ptr(bias) if bias is not None else None,
+            _ptr(o_t) if o_t is not None else None, o_ld, o_coff, _ptr(p_t) if p_t is not None else None, p_ld, p_coff, p_rows,
+            None, b, h, w, cout, stride, act, self.WSHIFT, _stream()))
+        _abi.check(code, 'um_conv7_fwd')
+
+    def nhwc_gate(self, mode, src, dest, ld, coff, rows, channels, zr=None, hbuf=None):
+        """``um_nhwc_gate``: column scatter (0), ``r * h`` (1), GRU state update (2) into ``dest`` planes ``[2][.][ld]``."""
+        p_rows = dest.numel() // (4 * ld) if dest is not None else 0
+        src_ld = src.shape[1] if src is not None else 0
+        code = self._launch('instance_norm', lambda: self.lib.um_nhwc_gate(
+            mode, _ptr(src) if src is not None else None, src_ld, _ptr(zr) if zr is not None else None,
+            _ptr(hbuf) if hbuf is not None else None, _ptr(dest) if dest is not None else None, ld, coff, p_rows, rows, channels,
+            _stream()))
+        _abi.check(code, 'um_nhwc_gate')
+
+    def local_corr_with_flow_planes(self, f0, f1, flow, h, w, radius, dest, ld):
+        """K4 written channels-last as operand planes (``um_local_corr_with_flow_planes``)."""
+        b, l, c = f0.shape
+        _check_tokens('f0', f0, tokens=h * w)
+        _check_tokens('f1', f1, b, l)
+        flow = flow.contiguous()
+        code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_planes(
+            _ptr(f0), _ptr(f1), _ptr(flow), _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius, _stream()))
+        _abi.check(code, 'um_local_corr_with_flow_planes')
+
     def stem_conv(self, image, weight, norm_mean_std=None, stats=True):
         """The encoder's 7x7/2 stem on ``um_stem_conv_fwd``: fp32 NCHW image ``[b,3,h,w]`` -> fp32 NHWC ``[b*ho*wo, cout]``.
         ``norm_mean_std``: ``((m0,m1,m2), (s0,s1,s2))`` applies the reference's ``(x / 255 - mean) / std`` while packing."""

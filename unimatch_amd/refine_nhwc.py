@@ -1,0 +1,123 @@
+"""The regression refinement block (``BasicUpdateBlock``, /root/reference/unimatch/reg_refine.py:79-119) in channels-last
+layout on the library's matrix-core convolutions -- SURVEY.md 8(f) rank 3.
+
+Same parameters and arithmetic as :class:`unimatch_amd.refine.BasicUpdateBlock` (which stays the CPU / reference path);
+what changes is the data flow:
+
+* the local cost volume (K4, ``um_local_corr_with_flow_planes``) is written directly as the operand planes of the motion
+  encoder's 1x1 convolution -- the fp32 ``[B, 81, h, w]`` volume never exists;
+* every convolution (``um_conv2d_ex`` / ``um_conv7_fwd``) writes the NEXT convolution's operand planes from its epilogue,
+  with ReLU / sigmoid / tanh fused; the four ``torch.cat`` of the block are column offsets into shared buffers:
+      CF  [256] = convc2 out (192) | convf2 out (64)
+      G   [512] = h (128) | inp (128) | motion (128 - fd) | flow (fd) | r * h (128)
+  so ``hx = cat(h, x)`` is columns 0..384 of G and ``cat(r * h, x)`` is columns 128..512 read with the q-gate weight's input
+  channels permuted to (x, r * h);
+* the z and r gates are one convolution (256 outputs, sigmoid epilogue);
+* the mask head only runs in the iteration whose mask is used (the reference computes and discards the others).
+"""
+import torch
+
+
+class NhwcUpdateBlock:
+    def __init__(self, ops, block, proj):
+        self.ops, self.block, self.proj = ops, block, proj
+        self.fd = block.flow_head.conv2.out_channels                 # flow channels: 2 (flow) or 1 (disparity / depth)
+
+    # ---------------------------------------------------------------- weights (prepared once per parameter version)
+    def _w(self, tag, params, build):
+        key, hit = self.ops._cache_get(('refine', tag), tuple(params))
+        if hit is None:
+            with torch.no_grad():
+                w, b = build()
+                planes = self.ops.conv_weight_planes_from(w)
+                hit = self.ops._cache_put(key, tuple(params), (planes, None if b is None else b.float().contiguous()))
+        return hit
+
+    @staticmethod
+    def _pad(t, dim, to):
+        if t.shape[dim] == to:
+            return t
+        shape = list(t.shape)
+        shape[dim] = to - t.shape[dim]
+        return torch.cat([t, t.new_zeros(shape)], dim)
+
+    def _weights(self):
+        enc, gru, fh, fd = self.block.encoder, self.block.gru, self.block.flow_head, self.fd
+        w = {}
+        w['proj'] = self._w('proj', [self.proj.weight, self.proj.bias], lambda: (self.proj.weight, self.proj.bias))
+        w['c1'] = self._w('c1', [enc.convc1.weight, enc.convc1.bias],
+                          lambda: (self._pad(enc.convc1.weight, 1, 96), enc.convc1.bias))
+        w['c2'] = self._w('c2', [enc.convc2.weight, enc.convc2.bias], lambda: (enc.convc2.weight, enc.convc2.bias))
+        w['f2'] = self._w('f2', [enc.convf2.weight, enc.convf2.bias], lambda: (enc.convf2.weight, enc.convf2.bias))
+        w['mo'] = self._w('mo', [enc.conv.weight, enc.conv.bias],
+                          lambda: (self._pad(enc.conv.weight, 0, 128), self._pad(enc.conv.bias, 0, 128)))
+        for tag in ('1', '2'):
+            z, r, q = (getattr(gru, f'conv{g}{tag}') for g in 'zrq')
+            w['zr' + tag] = self._w('zr' + tag, [z.weight, z.bias, r.weight, r.bias],
+                                    lambda z=z, r=r: (torch.cat([z.weight, r.weight], 0), torch.cat([z.bias, r.bias], 0)))
+            w['q' + tag] = self._w('q' + tag, [q.weight, q.bias],
+                                   lambda q=q: (torch.cat([q.weight[:, 128:], q.weight[:, :128]], 1), q.bias))
+        w['fh1'] = self._w('fh1', [fh.conv1.weight, fh.conv1.bias], lambda: (fh.conv1.weight, fh.conv1.bias))
+        w['fh2'] = self._w('fh2', [fh.conv2.weight, fh.conv2.bias],
+                           lambda: (self._pad(fh.conv2.weight, 0, 4), self._pad(fh.conv2.bias, 0, 4)))
+        if self.block.mask is not None:
+            m1, m2 = self.block.mask[0], self.block.mask[2]
+            w['m1'] = self._w('m1', [m1.weight, m1.bias], lambda: (m1.weight, m1.bias))
+            w['m2'] = self._w('m2', [m2.weight, m2.bias], lambda: (m2.weight, m2.bias))
+        return w
+
+    # ---------------------------------------------------------------- per scale
+    def begin(self, f0_tokens, b, h, w):
+        """``f0_tokens [b, h*w, 128]``: the (transformer) features the block's hidden state / context are projected from."""
+        ops = self.ops
+        self.b, self.h, self.w = b, h, w
+        rows = self.rows = b * h * w
+        self.wts = self._weights()
+        self.G = ops.planes_buffer(rows, 512)
+        self.C1, self.CF, self.FH = (ops.planes_buffer(rows, 256) for _ in range(3))
+        self.F1 = ops.planes_buffer(rows, 128)
+        self.CORR = ops.planes_buffer(rows, 96)
+        fp, _ = ops.nhwc_planes_from([f0_tokens.reshape(rows, 128)])
+        proj = torch.empty((rows, 256), dtype=torch.float32, device=f0_tokens.device)
+        ops.conv_ex((fp, 128, 0, 128), (b, h, w), self.wts['proj'], (1, 1), 1, (0, 0), 0, out=(proj, 256, 0))
+        self.net0 = torch.tanh(proj[:, :128]).contiguous()            # unimatch.py:317-320
+        inp = torch.relu(proj[:, 128:]).contiguous()
+        ops.nhwc_gate(0, inp, self.G, 512, 128, rows, 128)
+        self.H = torch.empty_like(self.net0)
+        self.ZR = torch.empty((rows, 256), dtype=torch.float32, device=proj.device)
+        self.Q = torch.empty((rows, 128), dtype=torch.float32, device=proj.device)
+        self.D = torch.empty((rows, 4), dtype=torch.float32, device=proj.device)
+
+    def iterate(self, ori0, ori1, disp, flow, want_mask):
+        """One refinement iteration.  ``disp [b,2,h,w]``: sampling offsets of the cost volume, ``flow [b,fd,h,w]``: the
+        current estimate.  Returns ``(mask_nhwc | None, delta [b,fd,h,w])``."""
+        ops, b, h, w, rows, fd, W = self.ops, self.b, self.h, self.w, self.rows, self.fd, self.wts
+        g = (b, h, w)
+        ops.local_corr_with_flow_planes(ori0, ori1, disp, h, w, 4, self.CORR, 96)
+        # motion encoder (reg_refine.py:6-36)
+        ops.conv_ex((self.CORR, 96, 0, 96), g, W['c1'], (1, 1), 1, (0, 0), 1, outp=(self.C1, 256, 0))
+        ops.conv_ex((self.C1, 256, 0, 256), g, W['c2'], (3, 3), 1, (1, 1), 1, outp=(self.CF, 256, 0))
+        enc = self.block.encoder
+        ops.conv7(flow, enc.convf1.weight, enc.convf1.bias, 1, 1, outp=(self.F1, 128, 0))
+        ops.conv_ex((self.F1, 128, 0, 128), g, W['f2'], (3, 3), 1, (1, 1), 1, outp=(self.CF, 256, 192))
+        ops.conv_ex((self.CF, 256, 0, 256), g, W['mo'], (3, 3), 1, (1, 1), 1, outp=(self.G, 512, 256))
+        ops.nhwc_gate(0, flow.permute(0, 2, 3, 1).reshape(rows, fd).contiguous(), self.G, 512, 384 - fd, rows, fd)
+        # SepConvGRU (reg_refine.py:55-76); the hidden state restarts from net0 every iteration (unimatch.py:322-331)
+        self.H.copy_(self.net0)
+        ops.nhwc_gate(0, self.H, self.G, 512, 0, rows, 128)
+        for tag, ks, pad in (('1', (1, 5), (0, 2)), ('2', (5, 1), (2, 0))):
+            ops.conv_ex((self.G, 512, 0, 384), g, W['zr' + tag], ks, 1, pad, 2, out=(self.ZR, 256, 0))
+            ops.nhwc_gate(1, None, self.G, 512, 384, rows, 128, zr=self.ZR, hbuf=self.H)
+            ops.conv_ex((self.G, 512, 128, 384), g, W['q' + tag], ks, 1, pad, 3, out=(self.Q, 128, 0))
+            ops.nhwc_gate(2, self.Q, self.G, 512, 0, rows, 128, zr=self.ZR, hbuf=self.H)
+        # flow head (reg_refine.py:39-52)
+        ops.conv_ex((self.G, 512, 0, 128), g, W['fh1'], (3, 3), 1, (1, 1), 1, outp=(self.FH, 256, 0))
+        ops.conv_ex((self.FH, 256, 0, 256), g, W['fh2'], (3, 3), 1, (1, 1), 0, out=(self.D, 4, 0))
+        delta = self.D[:, :fd].reshape(b, h, w, fd).permute(0, 3, 1, 2).contiguous()
+        mask = None
+        if want_mask and self.block.mask is not None:
+            ops.conv_ex((self.G, 512, 0, 128), g, W['m1'], (3, 3), 1, (1, 1), 1, outp=(self.FH, 256, 0))
+            cm = self.block.mask[2].out_channels
+            mask = torch.empty((rows, cm), dtype=torch.float32, device=self.D.device)
+            ops.conv_ex((self.FH, 256, 0, 256), g, W['m2'], (1, 1), 1, (0, 0), 0, out=(mask, cm, 0))
+        return mask, delta
