@@ -1,4 +1,6 @@
-"""CNN feature encoder (stays on PyTorch-ROCm / MIOpen: dense convolutions are outside the hot path).
+"""CNN feature encoder.  On the GPU it runs channels-last on the library's convolution / InstanceNorm kernels
+(``_forward_nhwc``: ``um_conv7_fwd`` stem, ``um_conv2d_fwd``, ``um_nhwc_instance_norm``); the stock ``nn.Conv2d`` modules below hold
+the parameters and are the CPU path.
 
 Architecture and parameter names follow /root/reference/unimatch/backbone.py:39-133 and
 unimatch/trident_conv.py:10-90 so that reference checkpoints load unchanged

@@ -1,4 +1,5 @@
-"""RAFT-style regression refinement block and convex upsampling (PyTorch-ROCm / MIOpen; outside the hot path).
+"""RAFT-style regression refinement block and convex upsampling: parameter container + CPU path (on the GPU the block runs
+channels-last on the library's convolutions, ``unimatch_amd/refine_nhwc.py``).
 
 Parameter names follow /root/reference/unimatch/reg_refine.py (``refine.encoder.convc1.weight``,
 ``refine.gru.convz1.bias``, ``refine.flow_head.conv2.weight``, ``refine.mask.2.weight`` ...).  The block's
