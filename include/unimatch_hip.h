@@ -87,11 +87,13 @@ int um_window_attn_fwd(const float* q, const float* k, const float* v, float* ou
 /* Same attention core on operands that are ALREADY in the MFMA plane format ([NS][rows][ld] 16-bit, NS = 2 fp16
  * planes hi|lo in UM_MODE_EXACT, 1 bf16 plane in UM_MODE_FAST; plane stride = rows * ld elements), e.g. the output
  * of um_linear_fwd(epilogue = UM_EPI_PLANES).  q/k/v may be column slices of wider projections: ldq / ldkv are
- * the row strides in elements (multiples of 8), rows = streams * h * w.  k and v share ldkv.  No workspace. */
+ * the row strides in elements (multiples of 8), rows = streams * h * w.  k and v share ldkv.  No workspace.
+ * kv_rotate: stream s reads the keys / values of stream (s + kv_rotate) mod streams -- with streams = 2B and kv_rotate = B this
+ * is the reference's cross attention of [f0; f1] against [f1; f0] (unimatch/transformer.py:271-291) without the swapped copy. */
 int um_window_attn_planes_fwd(const void* q_planes, const void* k_planes, const void* v_planes, float* out,
                               int streams, int h, int w, int channels, int ldq, int ldkv,
                               long q_plane_stride, long kv_plane_stride,
-                              int win_h, int win_w, int shift_h, int shift_w, int mode, void* stream);
+                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Transformer-layer linears  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear without bias) on MFMA with fused

@@ -45,6 +45,7 @@ struct WattnArgs {
     float* out;                  // [S][L][128]
     int h, w, win_h, win_w, shift_h, shift_w;
     int nwx, nwin;               // windows per row, windows per stream
+    int streams, kv_rotate;
     int n;                       // tokens per window
     int nqt;                     // 128-query tiles per window
     int total;                   // workgroups
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const bool has_mask = (a.shift_h > 0 && (wy + 1) * a.win_h == a.h) || (a.shift_w > 0 && (wx + 1) * a.win_w == a.w);
     const float c = a.scale_log2;
     const long sbase = (long)s * a.h * a.w;
+    // keys / values of stream (s + kv_rotate) mod streams: cross attention between the two halves of one stream tensor
+    // ([f0; f1] attends [f1; f0], unimatch/transformer.py:271-291) without materialising the swapped copy
+    const long kvbase = (long)((s + a.kv_rotate) % a.streams) * a.h * a.w;
 
     // ---- this lane's query -----------------------------------------------------------------------
     const int tq = qt * 128 + wave * 32 + (lane & 31);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             int cls;
             const int tok = token_at(sly[j], slx[j], cls);
             advance(sly[j], slx[j]);
-            const long goff = (sbase + tok) * a.ldkv;
+            const long goff = (kvbase + tok) * a.ldkv;
             spk[j] = a.kp + goff + ssrc_k[j];
             spv[j] = a.vp + goff + ssrc_v[j];
         }
@@ -452,7 +456,7 @@ extern "C" int um_debug_set_trace(void* ptr) {
 
 static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
-                              int win_h, int win_w, int shift_h, int shift_w, int mode, hipStream_t stream);
+                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream);
 
 static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
                                int mode) {
@@ -484,7 +488,7 @@ static int check_attn_geometry(int streams, int h, int w, int channels, int win_
 extern "C" int um_window_attn_planes_fwd(const void* qp, const void* kp, const void* vp, float* out, int streams,
                                          int h, int w, int channels, int ldq, int ldkv, long q_plane_stride,
                                          long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w,
-                                         int mode, void* stream) {
+                                         int kv_rotate, int mode, void* stream) {
     if (!qp || !kp || !vp || !out) {
         um_set_error("null pointer");
         return -1;
@@ -496,7 +500,7 @@ extern "C" int um_window_attn_planes_fwd(const void* qp, const void* kp, const v
     }
     return launch_window_attn((const unsigned short*)qp, (const unsigned short*)kp, (const unsigned short*)vp, out,
                               streams, h, w, ldq, ldkv, q_plane_stride, kv_plane_stride, win_h, win_w, shift_h, shift_w,
-                              mode, (hipStream_t)stream);
+                              kv_rotate, mode, (hipStream_t)stream);
 }
 
 extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
@@ -530,13 +534,15 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
     if ((e = launch_split_planes(v, pv, streams * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
 
     return launch_window_attn(pq, pk, pv, out, streams, h, w, UM_CHANNELS, UM_CHANNELS, streams * L * UM_CHANNELS,
-                              streams * L * UM_CHANNELS, win_h, win_w, shift_h, shift_w, mode, stream);
+                              streams * L * UM_CHANNELS, win_h, win_w, shift_h, shift_w, 0, mode, stream);
 }
 
 static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
-                              int win_h, int win_w, int shift_h, int shift_w, int mode, hipStream_t stream) {
+                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream) {
     WattnArgs a;
+    a.streams = streams;
+    a.kv_rotate = ((kv_rotate % streams) + streams) % streams;
     a.qp = pq;
     a.kp = pk;
     a.vp = pv;

@@ -108,9 +108,12 @@ class TransformerLayer(nn.Module):
                                      nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
             self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, ops, source, target, h, w, geom):
+    def forward(self, ops, source, target, h, w, geom, kv_rotate=0):
+        """``kv_rotate = r`` (fused path only): ``target`` holds the streams in the SAME order as ``source`` and stream ``s``
+        attends the keys / values of stream ``(s + r) mod S`` -- the swapped copy ``[f1; f0]`` is never built."""
         if getattr(ops, 'fused_tail', False):
-            return self._forward_fused(ops, source, target, h, w, geom)
+            return self._forward_fused(ops, source, target, h, w, geom, kv_rotate)
+        assert kv_rotate == 0
         q, k, v = self.q_proj(source), self.k_proj(target), self.v_proj(target)
         msg = ops.window_attention(q, k, v, h, w, *geom)
         msg = self.norm1(self.merge(msg))
@@ -118,7 +121,7 @@ class TransformerLayer(nn.Module):
             msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
         return source + msg
 
-    def _forward_fused(self, ops, source, target, h, w, geom):
+    def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0):
         """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
         (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``)."""
         s, l, c = source.shape
@@ -131,7 +134,7 @@ class TransformerLayer(nn.Module):
             qp, _, _ = ops.linear_planes(src, (self.q_proj.weight,))
             kv, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
             q, k, v = (qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c)
-        att = ops.window_attention_planes(q, k, v, s, h, w, *geom).reshape(m, c)
+        att = ops.window_attention_planes(q, k, v, s, h, w, *geom, kv_rotate=kv_rotate).reshape(m, c)
         if self.no_ffn:
             return ops.linear_ln(att, (self.merge.weight,), self.norm1, residual=src).reshape(s, l, c)
         msg = ops.linear_ln(att, (self.merge.weight,), self.norm1)
@@ -166,14 +169,19 @@ class FeatureTransformer(nn.Module):
         """tok0, tok1: ``[B, h*w, C]`` token-major features (position already added)."""
         b = tok0.shape[0]
         stream = torch.cat([tok0, tok1], 0)            # updated stream  [f0; f1]
-        other = torch.cat([tok1, tok0], 0)             # cross-attention target [f1; f0]
+        rotate = getattr(ops, 'fused_tail', False)     # cross-attention target [f1; f0] = `prev` read with the halves rotated
+        prev = stream if rotate else torch.cat([tok1, tok0], 0)
         for i, blk in enumerate(self.layers):
             shift = ('swin' in attn_type) and attn_num_splits > 1 and i % 2 == 1
             g_self = attention_windows(attn_type, True, attn_num_splits, h, w, shift)
             g_cross = attention_windows(attn_type, False, attn_num_splits, h, w, shift)
             stream = blk.self_attn(ops, stream, stream, h, w, g_self)
-            stream = blk.cross_attn_ffn(ops, stream, other, h, w, g_cross)
-            other = torch.cat([stream[b:], stream[:b]], 0)
+            if rotate:                                 # keys / values come from the stream as it was before this block
+                stream, prev = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b), None
+                prev = stream
+            else:
+                stream = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross)
+                prev = torch.cat([stream[b:], stream[:b]], 0)
         return stream[:b].contiguous(), stream[b:].contiguous()
 
 

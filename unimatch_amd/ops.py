@@ -204,7 +204,7 @@ class HipOps:
         _abi.check(code, 'um_ffn_fwd')
         return out
 
-    def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0):
+    def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0, kv_rotate=0):
         """Attention on operand planes.  q, k, v: ``(plane_tensor, rows, cols, col_offset)`` -- a 128-column slice
         starting at ``col_offset`` of a ``[NS][rows][cols]`` plane tensor (k and v must share their tensor's shape)."""
         (qt, qrows, qcols, qoff), (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = q, k, v
@@ -215,7 +215,7 @@ class HipOps:
         meta = {'flops': 4.0 * streams * h * w * n * 128}
         code = self._launch('window_attn', lambda: self.lib.um_window_attn_planes_fwd(
             _ptr(qt) + 2 * qoff, _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(out), streams, h, w, 128,
-            qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, self.mode, _stream()), meta)
+            qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
         _abi.check(code, 'um_window_attn_planes_fwd')
         return out
 
