@@ -20,11 +20,24 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     const long total = (long)batch * h * F * w;
     const long tix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= total) return;
-    const int x = (int)(tix % w);
-    const long t2 = tix / w;
-    const int fy = (int)(t2 % F);
-    const long t3 = t2 / F;
-    const int y = (int)(t3 % h), b = (int)(t3 / h);
+    int x, fy, y, b;
+    if (mask_cs == 1) {
+        // channels-last mask: the 9 F^2 logits of a pixel are contiguous, so consecutive lanes take consecutive sub-rows
+        // fy of one pixel (8 lanes read 256 contiguous bytes per tap)
+        fy = (int)(tix % F);
+        const long t2 = tix / F;
+        x = (int)(t2 % w);
+        const long t3 = t2 / w;
+        y = (int)(t3 % h);
+        b = (int)(t3 / h);
+    } else {
+        x = (int)(tix % w);
+        const long t2 = tix / w;
+        fy = (int)(t2 % F);
+        const long t3 = t2 / F;
+        y = (int)(t3 % h);
+        b = (int)(t3 / h);
+    }
     const int L = h * w, p = y * w + x;
     float nb[V][9];
 #pragma unroll
