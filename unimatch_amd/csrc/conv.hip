@@ -53,7 +53,8 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
 template <typename T, int NS, int NT>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     constexpr int TILE = 128 * 64;               // one 128-row x 64-byte operand tile (one plane, one stage)
-    constexpr int STAGE = 2 * NS * TILE;         // activation planes then weight planes (sized for NT = 4)
+    constexpr int WTILE = 32 * NT * 64;          // one weight plane of a stage: 32 NT output rows x 64 bytes
+    constexpr int STAGE = NS * (TILE + WTILE);   // activation planes then weight planes (NT = 2: 48 KB ring -> 3 WG / CU)
     constexpr int EPI = 4 * 32 * (32 * NT * 4);   // the epilogue's transposed tile
     constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 4 * 2 * 32 * NT * 4];   // + per-wave (mean, M2) columns
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
                 const unsigned off = (unsigned)(((long)n * ktot + kglob + 8 * sc) * 2);
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl)
-                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * TILE + pl * TILE + (32 * wave + 16 * i) * 64);
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * TILE + pl * WTILE + (32 * wave + 16 * i) * 64);
             }
         }
     };
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt) {
                 const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 64 + foff[ks]);
                 if (NS == 2) {
-                    const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + TILE + nt * 32 * 64 + foff[ks]);
+                    const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 64 + foff[ks]);
                     acc[nt] = T::mfma(wl, bh, acc[nt]);
                     acc[nt] = T::mfma(wh, bl, acc[nt]);
                 }
