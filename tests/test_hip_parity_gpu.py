@@ -394,6 +394,9 @@ def _nhwc_planes(ops, x_nchw):
     (2, 64, 64, 20, 28, 3, 3, 1, 1, 1, False, False),        # encoder layer1
     (1, 64, 96, 21, 30, 3, 3, 2, 1, 1, False, False),        # stride 2, odd size
     (2, 96, 96, 9, 13, 3, 3, 1, 1, 1, False, True),          # NT = 3 tile, fused ReLU
+    (2, 96, 96, 19, 23, 3, 3, 1, 1, 1, True, True),          # NT = 3, row-window kernel, ragged last tile
+    (3, 64, 64, 16, 24, 3, 3, 1, 1, 1, False, False),        # row-window kernel, tiles straddle rows and images
+    (1, 64, 64, 40, 7, 3, 3, 1, 1, 1, False, False),         # row-window kernel, image rows much shorter than a tile
     (1, 64, 96, 16, 24, 1, 1, 2, 0, 0, True, False),         # 1x1 projection shortcut with bias
     (1, 128, 128, 8, 12, 3, 3, 1, 1, 1, False, False),       # NT = 4
     (1, 128, 256, 7, 9, 3, 3, 1, 1, 1, True, True),          # two output tiles (flow head / mask head shape)

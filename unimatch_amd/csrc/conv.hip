@@ -16,6 +16,7 @@
 // LDS ring by LDS-DMA -- the only per-tap work is two row indices per lane.
 // Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
 // computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
+#include <cstdlib>
 #include "common.h"
 #include "planes.h"
 
@@ -48,6 +49,98 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
                  : "=&s"(keep)
                  : "v"(byte_off), "s"(base), "s"(dst)
                  : "memory");
+}
+
+// ---- epilogue shared by both kernels: lane holds, for pixel m0 + 32*wave + (lane & 31), outputs n0 + 32*nt + 8*g + 4*half + i
+// (reg 4*g + i).  `scratch` = LDS beyond the (now idle) staging ring: 2 * 32 NT floats per wave for the statistics.
+template <typename T, int NS, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
+                                              int m0, int n0, int tid, int wave, int lane, int half) {
+    // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
+    // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
+    constexpr int ROWB = 32 * NT * 4;                             // bytes per pixel row of the tile
+    unsigned char* stg = lds + wave * (32 * ROWB);
+    const int tl = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + 32 * nt + 8 * g + 4 * half;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[nt][4 * g + i] * a.out_scale;
+                if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
+                if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
+                else if (a.act == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
+                else if (a.act == 3) v[i] = tanhf(v[i]);
+            }
+            const int c = 8 * nt + 2 * g + half;                 // 16-byte chunk index inside the row
+            *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (a.stats) {
+        // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
+        // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
+        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  Only used when tiles do not
+        // straddle images (pixels per image a multiple of 128), so every row is valid here.
+        float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT);
+        for (int ch = lane; ch < 32 * NT; ch += 64) {
+            const int c = ch >> 2, ci = ch & 3;
+            const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const float d = *reinterpret_cast<const float*>(stg + r * ROWB + ((c ^ (r & 7)) << 4) + ci * 4) - k;
+                s1 += d;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+            ws[ch] = k + s1 * (1.0f / 32.0f);                               // mean of the wave's 32 pixels
+            ws[32 * NT + ch] = s2 - s1 * s1 * (1.0f / 32.0f);              // sum of squared deviations
+        }
+        __syncthreads();
+        // threads 0 .. 32 NT - 1 of every group of four waves merge that group's 128 pixels
+        const int grp = tid >> 8, gt = tid & 255;
+        if (gt < 32 * NT && n0 + gt < a.Cout && m0 + 128 * grp < a.M) {
+            const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT);
+            const int tid = gt;
+            float mean = w0[tid], m2 = w0[32 * NT + tid], n = 32.f;
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
+                const float delta = mw - mean, nn = n + 32.f;
+                mean += delta * (32.f / nn);
+                m2 += m2w + delta * delta * (n * 32.f / nn);
+                n = nn;
+            }
+            float* pr = a.stats + ((long)(m0 / 128 + grp) * 3) * a.Cout + n0 + tid;
+            pr[0] = mean;
+            pr[a.Cout] = 0.f;
+            pr[2 * a.Cout] = m2;
+        }
+    }
+    constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
+    constexpr int ITER = 32 * CPR / 64;
+    const int row0 = m0 + 32 * wave;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
+        if (row0 + r < a.M && n0 + 4 * c < a.Cout) {
+            if (a.out) *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.out_ld + a.out_coff + n0 + 4 * c) = d;
+            if (a.outp) {
+                unsigned short* dst = a.outp + (long)(row0 + r) * a.outp_ld + a.outp_coff + n0 + 4 * c;
+                const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
+                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                if (NS == 2) {
+                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
+                    *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
+                        u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                }
+            }
+        }
+    }
 }
 
 template <typename T, int NS, int NT>
@@ -94,8 +187,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             rowoff[i] = row * a.row_stride;
         }
     };
+    int ky = 0, kx = 0, cc = 0;                  // position of the NEXT stage to be issued
     // 16-byte chunk cp of row r holds source chunk cp ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
     auto stage_async = [&](int c0, int kglob, unsigned char* buf) {
+#ifdef UM_CONV_ABL_A
+        if (kx == 1 || a.KW != 3)
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * wave + 16 * i + (lane >> 2);
@@ -104,16 +201,18 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * TILE + (32 * wave + 16 * i) * 64);
         }
-        if (wave < NT) {
+        // the weight tile is 2 NT blocks of 16 rows; block j goes to wave j mod 4 (every wave issues its share)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = 32 * wave + 16 * i + (lane >> 2);
+        for (int i = 0; i < (2 * NT + 3) / 4; ++i) {
+            const int j = wave + 4 * i;
+            if (j < 2 * NT) {
+                const int r = 16 * j + (lane >> 2);
                 const int sc = dcp ^ ((r >> 2) & 3);
                 const int n = min(n0 + r, a.Cout - 1);
                 const unsigned off = (unsigned)(((long)n * ktot + kglob + 8 * sc) * 2);
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl)
-                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * TILE + pl * WTILE + (32 * wave + 16 * i) * 64);
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * TILE + pl * WTILE + (16 * j) * 64);
             }
         }
     };
@@ -131,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     for (int ks = 0; ks < 2; ++ks) foff[ks] = fr * 64 + (((2 * ks + half) ^ ((fr >> 2) & 3)) << 4);
 
     // ---- prologue: stage 0 ------------------------------------------------------------------------------------
-    int ky = 0, kx = 0, cc = 0;                  // position of the NEXT stage to be issued
     set_tap(0, 0);
     stage_async(0, 0, lds);
     auto advance = [&]() {                       // move (ky, kx, cc) one stage on; recompute the row offsets on a new tap
@@ -179,90 +277,192 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, for pixel m0 + 32*wave + (lane & 31), outputs n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i) ----
-    // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
-    // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
-    constexpr int ROWB = 32 * NT * 4;                             // bytes per pixel row of the tile
-    unsigned char* stg = lds + wave * (32 * ROWB);
-    const int tl = lane & 31;
+    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, m0, n0, tid, wave, lane, half);
+}
+
+// ---- row-window variant: same-size stride-1 convolutions with KW > 1 horizontal taps ------------------------------------------
+// In the generic kernel every tap stages its own [128 x 32] activation tile, although the KW horizontal taps of one kernel row
+// read the SAME input pixels shifted by one: with flat pixel indices (output and input images have the same shape) tap
+// (ky, kx) of output pixel p is input pixel p + (ky - ph) W + (kx - pw).  Here a workgroup of 8 waves owns 256 consecutive
+// output pixels and, per (ky, 32-channel chunk), stages ONE window of 256 + KW - 1 input rows that serves all KW taps
+// (fragment reads at row offset kx) next to the KW weight tiles: 2.5x fewer LDS-DMA instructions and 3x fewer barriers per
+// MFMA than the generic kernel at NT = 2 (its measured limiter).  Taps that cross the left / right image border are zeroed
+// per lane at fragment level; rows above / below the image (and outside the batch) are staged from the zero row.
+template <typename T, int NS, int NT, int KW>
+__global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
+    constexpr int WROWS = 272;                   // 17 DMA blocks of 16 rows >= 256 + KW - 1
+    constexpr int ATILE = WROWS * 64;            // one plane of the window
+    constexpr int WTILE = 32 * NT * 64;          // one plane of one tap's weight tile
+    constexpr int STAGE = NS * (ATILE + KW * WTILE);
+    constexpr int EPI = 8 * 32 * (32 * NT * 4);
+    constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, fr = lane & 31;
+    const int m0 = blockIdx.x * 256, n0 = blockIdx.y * (32 * NT);
+    const int cpt = a.Cin >> 5;
+    const int nstage = a.KH * cpt;
+    const int ktot = a.KH * KW * a.Cin;
+    const int hw = a.Ho * a.Wo;
+
+    // ---- window rows this lane stages: DMA block jr = wave + 8 i (16 rows each), row j = 16 jr + (lane >> 2) ----------------
+    // validity is decided by the row's "central" user, output pixel m0 + j - pw (see above)
+    const int dcp = lane & 3;
+    int wy[3];
+    long wflat[3];
+    bool wok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 16 * (wave + 8 * i) + (lane >> 2);
+        const long p = (long)m0 + j - a.pad_w;
+        wok[i] = (wave + 8 * i) < 17 && p >= 0 && p < a.M;
+        const long pp = wok[i] ? p : 0;
+        const int b = (int)(pp / hw), rem = (int)(pp - (long)b * hw);
+        wy[i] = rem / a.Wo - a.pad_h;
+        wflat[i] = pp - (long)a.pad_h * a.Wi;
+    }
+    unsigned rowoff[3];
+    auto set_ky = [&](int ky) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = wy[i] + ky;
+            const bool ok = wok[i] && (unsigned)iy < (unsigned)a.Hi;
+            const unsigned row = ok ? (unsigned)(wflat[i] + (long)ky * a.Wi) : a.zero_row;
+            rowoff[i] = row * a.row_stride;
+        }
+    };
+    // One staging "piece" = this wave's share of one DMA block (NS instructions).  Pieces 0..2: window blocks; 3..: weight
+    // blocks.  They are issued one by one between the MFMA groups of the previous stage (all eight waves of the workgroup
+    // run in lockstep, so a DMA burst at the top of the stage would leave the matrix pipe idle).
+    constexpr int NPIECE = 3 + (KW * 2 * NT + 7) / 8;
+    auto stage_piece = [&](int k, int ky, int cc, unsigned char* buf) {
+        if (k < 3) {
+            const int jr = wave + 8 * k;
+            if (jr < 17) {
+                const int r = 16 * jr + (lane >> 2);
+                const int sc = dcp ^ ((r >> 2) & 3);
+                const unsigned off = rowoff[k] + (unsigned)((cc * 32 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * ATILE + (16 * jr) * 64);
+            }
+        } else {
+            const int q = wave + 8 * (k - 3);
+            if (q < KW * 2 * NT) {
+                const int kx = q / (2 * NT), jb = q - kx * (2 * NT);
+                const int r = 16 * jb + (lane >> 2);
+                const int sc = dcp ^ ((r >> 2) & 3);
+                const int n = min(n0 + r, a.Cout - 1);
+                const unsigned off = (unsigned)(((long)n * ktot + (ky * KW + kx) * a.Cin + cc * 32 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * ATILE + (kx * NS + pl) * WTILE + (16 * jb) * 64);
+            }
+        }
+    };
+
+    // ---- this lane's output pixel: which horizontal taps stay inside its image row ---------------------------------------
+    bool tap_ok[KW];
+    bool any_masked = false;
+    {
+        const long p = (long)m0 + 32 * wave + fr;
+        const bool pok = p < a.M;
+        const int x = (int)((pok ? p : 0) % a.Wo);
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            tap_ok[kx] = pok && (unsigned)(x + kx - a.pad_w) < (unsigned)a.Wi;
+            any_masked |= !tap_ok[kx];
+        }
+    }
+    const bool wave_masked = __any(any_masked);                   // wave uniform
+
+    f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + 32 * nt + 8 * g + 4 * half;
-            f32x4 v;
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // fragment offsets: weights row fr; activations window row 32 wave + fr + kx
+    int foffw[2], foffa[KW][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = acc[nt][4 * g + i] * a.out_scale;
-                if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
-                if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
-                else if (a.act == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
-                else if (a.act == 3) v[i] = tanhf(v[i]);
-            }
-            const int c = 8 * nt + 2 * g + half;                 // 16-byte chunk index inside the row
-            *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
-        }
-    __builtin_amdgcn_wave_barrier();
-    if (a.stats) {
-        // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
-        // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
-        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  Only used when tiles do not
-        // straddle images (pixels per image a multiple of 128), so every row is valid here.
-        float* ws = reinterpret_cast<float*>(lds + RING) + wave * (2 * 32 * NT);
-        for (int ch = lane; ch < 32 * NT; ch += 64) {
-            const int c = ch >> 2, ci = ch & 3;
-            const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const float d = *reinterpret_cast<const float*>(stg + r * ROWB + ((c ^ (r & 7)) << 4) + ci * 4) - k;
-                s1 += d;
-                s2 = __builtin_fmaf(d, d, s2);
-            }
-            ws[ch] = k + s1 * (1.0f / 32.0f);                               // mean of the wave's 32 pixels
-            ws[32 * NT + ch] = s2 - s1 * s1 * (1.0f / 32.0f);              // sum of squared deviations
-        }
-        __syncthreads();
-        if (tid < 32 * NT && n0 + tid < a.Cout) {
-            const float* w0 = reinterpret_cast<const float*>(lds + RING);
-            float mean = w0[tid], m2 = w0[32 * NT + tid], n = 32.f;
+    for (int ks = 0; ks < 2; ++ks) {
+        foffw[ks] = fr * 64 + (((2 * ks + half) ^ ((fr >> 2) & 3)) << 4);
 #pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
-                const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
-                const float delta = mw - mean, nn = n + 32.f;
-                mean += delta * (32.f / nn);
-                m2 += m2w + delta * delta * (n * 32.f / nn);
-                n = nn;
-            }
-            float* pr = a.stats + ((long)blockIdx.x * 3) * a.Cout + n0 + tid;
-            pr[0] = mean;
-            pr[a.Cout] = 0.f;
-            pr[2 * a.Cout] = m2;
+        for (int kx = 0; kx < KW; ++kx) {
+            const int r = 32 * wave + fr + kx;
+            foffa[kx][ks] = r * 64 + (((2 * ks + half) ^ ((r >> 2) & 3)) << 4);
         }
     }
-    constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
-    constexpr int ITER = 32 * CPR / 64;
-    const int row0 = m0 + 32 * wave;
+
+    // ---- prologue: stage 0 ------------------------------------------------------------------------------------------------
+    int ky = 0, cc = 0;                          // position of the NEXT stage to be issued
+    set_ky(0);
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int idx = it * 64 + lane;
-        const int r = idx / CPR, c = idx - r * CPR;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-        if (row0 + r < a.M && n0 + 4 * c < a.Cout) {
-            if (a.out) *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.out_ld + a.out_coff + n0 + 4 * c) = d;
-            if (a.outp) {
-                unsigned short* dst = a.outp + (long)(row0 + r) * a.outp_ld + a.outp_coff + n0 + 4 * c;
-                const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
-                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-                if (NS == 2) {
-                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                    *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
-                        u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+    for (int k = 0; k < NPIECE; ++k) stage_piece(k, 0, 0, lds);
+    auto advance = [&]() {
+        if (++cc == cpt) {
+            cc = 0;
+            ++ky;
+            set_ky(ky);
+        }
+    };
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = 0; s < nstage; ++s) {
+        unsigned char* cur = lds + (s & 1) * STAGE;
+        unsigned char* nxt = lds + ((s & 1) ^ 1) * STAGE;
+        const bool more = s + 1 < nstage;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const unsigned char* wt = cur + NS * ATILE + kx * NS * WTILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (more) {                                       // this group's share of the next stage's pieces
+                    constexpr int GROUPS = 2 * KW - 2;            // the last two groups issue nothing: their DMA would be
+                    const int g = 2 * kx + ks;                    // waited for at once
+#pragma unroll
+                    for (int k = 0; k < NPIECE; ++k)
+                        if (k % GROUPS == g && g < GROUPS) stage_piece(k, ky, cc, nxt);
+                }
+                i16x8 bh = *reinterpret_cast<const i16x8*>(cur + foffa[kx][ks]);
+                i16x8 bl;
+                if (NS == 2) bl = *reinterpret_cast<const i16x8*>(cur + ATILE + foffa[kx][ks]);
+                if (wave_masked && !tap_ok[kx]) {                  // this lane's tap is in the neighbouring image row
+                    const i16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    bh = z;
+                    bl = z;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 64 + foffw[ks]);
+                    if (NS == 2) {
+                        const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 64 + foffw[ks]);
+                        acc[nt] = T::mfma(wl, bh, acc[nt]);
+                        acc[nt] = T::mfma(wh, bl, acc[nt]);
+                    }
+                    acc[nt] = T::mfma(wh, bh, acc[nt]);
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
+    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, m0, n0, tid, wave, lane, half);
 }
+
+template <int NS, int NT, int KW>
+struct ConvRowsLds {
+    static constexpr int STAGE = NS * (272 * 64 + KW * 32 * NT * 64);
+    static constexpr int EPI = 8 * 32 * (32 * NT * 4);
+    static constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4;
+};
 
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
@@ -275,6 +475,32 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
         hipLaunchKernelGGL((conv_kernel<Fp16, 2, NT>), grid, block, 0, stream, a);
     else
         hipLaunchKernelGGL((conv_kernel<Bf16, 1, NT>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int NT, int KW>
+static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stream) {
+    static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
+    dim3 grid((a.M + 255) / 256, (a.Cout + 32 * NT - 1) / (32 * NT)), block(512);
+    constexpr int LDS2 = ConvRowsLds<2, NT, KW>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW>::TOTAL;
+    ScopedKernelTimer timer(UM_K_CONV, stream);
+    if (mode == 0) {
+        if (!configured[0]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Fp16, 2, NT, KW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            if (e != hipSuccess) return e;
+            configured[0] = true;
+        }
+        hipLaunchKernelGGL((conv_rows_kernel<Fp16, 2, NT, KW>), grid, block, LDS2, stream, a);
+    } else {
+        if (!configured[1]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Bf16, 1, NT, KW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            if (e != hipSuccess) return e;
+            configured[1] = true;
+        }
+        hipLaunchKernelGGL((conv_rows_kernel<Bf16, 1, NT, KW>), grid, block, LDS1, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -342,10 +568,15 @@ extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_r
     a.out_scale = ldexpf(1.f, -wshift);
     hipError_t e;
     // widest output tile that does not waste more than a third of its columns
-    if (cout % 128 == 0 || cout > 192) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
-    else if (cout % 96 == 0) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
-    else if (cout <= 64 || cout % 64 == 0) e = launch_conv<2>(a, mode, (hipStream_t)stream_);
-    else e = launch_conv<4>(a, mode, (hipStream_t)stream_);
+    const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
+    // same-size stride-1 3-tap rows: the row-window kernel (its LDS budget allows 64- and 96-wide output tiles)
+    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && m >= 256 &&
+                      getenv("UM_CONV_NO_ROWS") == nullptr;
+    if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
+    else if (rows && nt == 3) e = launch_conv_rows<3, 3>(a, mode, (hipStream_t)stream_);
+    else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
+    else if (nt == 3) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
+    else e = launch_conv<2>(a, mode, (hipStream_t)stream_);
     if (e != hipSuccess) {
         um_set_error("um_conv2d: launch failed: %s", hipGetErrorString(e));
         return (int)e;
