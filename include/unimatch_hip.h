@@ -270,6 +270,12 @@ int um_convex_upsample(const float* flow, const float* mask, float* up, int batc
                        int factor, int is_depth, int mask_nhwc, void* stream);
 /* mask_nhwc: the mask is [batch][h*w][9*factor^2] (the output of um_conv2d_fwd) instead of NCHW. */
 
+/* flow_warp (unimatch/geometry.py:41-72, call sites unimatch/unimatch.py:166-168): bilinear warp of a token-major feature
+ * [batch][h*w][channels] by flow [batch][2][h][w] (x, y), zeros outside, align_corners -> out_tokens, same layout.
+ * SURVEY.md 8(f) rank 2. */
+int um_flow_warp(const float* feature_tokens, const float* flow, float* out_tokens, int batch, int h, int w, int channels,
+                 void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Encoder helper (outside the hot path of SURVEY.md section 8; added because the element-wise tail of the CNN encoder
  * had become the largest non-convolution cost):  fused InstanceNorm2d(affine=False) + ReLU (+ shortcut + ReLU),

@@ -421,6 +421,20 @@ def test_conv2d_nhwc_matches_fp64(ops, case):
     assert err(got, want)[0] < 3e-6 * max(1.0, want.abs().max().item())
 
 
+def test_flow_warp(ops):
+    """um_flow_warp against the oracle's grid_sample warp in fp64: sub-pixel offsets, samples leaving the image on every
+    side (zeros padding), exact integer offsets."""
+    b, h, w, c = 2, 13, 17, 128
+    feat = rnd(110, b, c, h, w)
+    flow = rnd(111, b, 2, h, w, scale=4.0)
+    flow[0, :, :3] = torch.tensor([2.0, -1.0]).view(2, 1, 1)          # integer offsets
+    flow[1, :, -2:] = 40.0                                             # far outside
+    want = om.warp(feat.double(), flow.double())
+    tok = feat.flatten(2).transpose(1, 2).contiguous()
+    got = ops.flow_warp(tok.to(DEV), flow.to(DEV), h, w).transpose(1, 2).reshape(b, c, h, w)
+    assert err(got, want)[0] < 2e-5
+
+
 @pytest.mark.parametrize('fd,hw', [(2, (16, 24)), (1, (12, 20))])
 def test_nhwc_update_block_matches_module(ops, fd, hw):
     """The channels-last refinement block (refine_nhwc.NhwcUpdateBlock: K4 -> planes, concat-free convolution chain, fused

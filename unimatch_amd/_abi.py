@@ -43,6 +43,7 @@ SIGNATURES = {
     'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_void_p,
                                        _c_size_t, _c_int, _c_void_p]),
     'um_nchw_to_nhwc': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
+    'um_flow_warp': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_convex_upsample': (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),
     'um_instance_norm_fwd': (_c_int, [_c_void_p] * 3 + [ctypes.c_long, _c_int, ctypes.c_float, _c_int, _c_void_p]),
     'um_global_corr_workspace_bytes': (_c_size_t, [_c_int] * 4),

@@ -82,6 +82,42 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     }
 }
 
+// ---- flow_warp (unimatch/geometry.py:41-72): out[b, p, :] = bilinear sample of the token-major feature at p + flow[b, :, p],
+// zeros outside, align_corners.  One thread = 4 channels of one pixel (32 threads cover a 128-channel token row, so every tap
+// is one coalesced 512-byte read).  The coordinate arithmetic repeats the reference's normalise / un-normalise round trip
+// (2 x / (w - 1) - 1, then ((g + 1) / 2) (w - 1) inside grid_sample) so that the fp32 rounding is the same.
+__global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict__ feat, const float* __restrict__ flow,
+                                                        float* __restrict__ out, int batch, int h, int w, int c4n) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int L = h * w;
+    if (idx >= (long)batch * L * c4n) return;
+    const int cq = (int)(idx % c4n);
+    const long pid = idx / c4n;
+    const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+    const int y = p / w, x = p - y * w;
+    const float px = (float)x + flow[((long)b * 2) * L + p], py = (float)y + flow[((long)b * 2 + 1) * L + p];
+    const float gx = 2.0f * px / (float)(w - 1) - 1.0f, gy = 2.0f * py / (float)(h - 1) - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    const float wnw = (fx1 - ix) * (fy1 - iy), wne = (ix - fx0) * (fy1 - iy);
+    const float wsw = (fx1 - ix) * (iy - fy0), wse = (ix - fx0) * (iy - fy0);
+    const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), y0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+    const float* fb = feat + ((long)b * L) * (4 * c4n) + 4 * cq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto tap = [&](int yy, int xx, float wt) {
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (long)(yy * w + xx) * (4 * c4n));
+            acc += v * wt;
+        }
+    };
+    tap(y0, x0, wnw);
+    tap(y0, x0 + 1, wne);
+    tap(y0 + 1, x0, wsw);
+    tap(y0 + 1, x0 + 1, wse);
+    *reinterpret_cast<f32x4*>(out + pid * (4 * c4n) + 4 * cq) = acc;
+}
+
 extern void um_set_error(const char* fmt, ...);
 
 extern "C" int um_convex_upsample(const float* flow, const float* mask, float* up, int batch, int channels, int h, int w,
@@ -108,5 +144,19 @@ extern "C" int um_convex_upsample(const float* flow, const float* mask, float* u
         hipLaunchKernelGGL((convex_upsample_kernel<4, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
     else
         hipLaunchKernelGGL((convex_upsample_kernel<4, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int um_flow_warp(const float* feature_tokens, const float* flow, float* out_tokens, int batch, int h, int w,
+                            int channels, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!feature_tokens || !flow || !out_tokens || batch <= 0 || h < 2 || w < 2 || channels <= 0 || channels % 4 != 0) {
+        um_set_error("um_flow_warp: bad argument (batch=%d h=%d w=%d channels=%d)", batch, h, w, channels);
+        return -1;
+    }
+    const long total = (long)batch * h * w * (channels / 4);
+    ScopedKernelTimer timer(UM_K_CONVEX_UPSAMPLE, stream);
+    hipLaunchKernelGGL(flow_warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feature_tokens, flow,
+                       out_tokens, batch, h, w, channels / 4);
     return (int)hipGetLastError();
 }

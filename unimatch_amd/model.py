@@ -383,7 +383,10 @@ class UniMatch(nn.Module):
                 if flow is not None:
                     assert task != 'depth'
                     disp = torch.cat([-flow, torch.zeros_like(flow)], 1) if task == 'stereo' else flow
-                    tok1 = _to_tokens(_warp(m1, disp))
+                    if hasattr(ops, 'flow_warp') and ori1.is_cuda:
+                        tok1 = ops.flow_warp(ori1, disp.contiguous(), h, w)
+                    else:
+                        tok1 = _to_tokens(_warp(m1, disp))
                 splits, prop_r = attn_splits_list[s], prop_radius_list[s]
                 pos = self._position(h, w, splits, dev)
                 tok0, tok1 = ori0 + pos, tok1 + pos

@@ -234,6 +234,19 @@ class HipOps:
         _abi.check(code, 'um_convex_upsample')
         return up
 
+    def flow_warp(self, tokens, flow, h, w):
+        """``um_flow_warp``: bilinear warp of token-major features ``[b, h*w, c]`` by ``flow [b,2,h,w]`` -> tokens."""
+        b, l, c = tokens.shape
+        if not (tokens.is_cuda and tokens.dtype == torch.float32 and tokens.is_contiguous() and l == h * w
+                and tuple(flow.shape) == (b, 2, h, w) and flow.dtype == torch.float32):
+            raise ValueError(f'flow_warp: bad shapes tokens {tuple(tokens.shape)} flow {tuple(flow.shape)}')
+        flow = flow.contiguous()
+        out = torch.empty_like(tokens)
+        code = self._launch('convex_upsample', lambda: self.lib.um_flow_warp(
+            _ptr(tokens), _ptr(flow), _ptr(out), b, h, w, c, _stream()))
+        _abi.check(code, 'um_flow_warp')
+        return out
+
     # ------------------------------------------------------------------ encoder helper (outside the hot path)
     def instance_norm(self, x, relu=True, shortcut=None, eps=1e-5):
         """Fused InstanceNorm2d(affine=False) [+ ReLU] [+ shortcut, ReLU] on a contiguous NCHW fp32 map."""
