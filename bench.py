@@ -163,7 +163,7 @@ def main():
     # ---- CPU baseline: the pinned port of the reference, bounded sample, same workload shape
     cpu = None
     epe = {}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1 and rank == 0:      # reported baseline: rank 0 of the 1-GPU run only
         from oracle import model as om
         c0, c1 = i0[:1].cpu(), i1[:1].cpu()
         okw = dict(fk, num_scales=ck['num_scales'], upsample_factor=ck['upsample_factor'], reg_refine=ck['reg_refine'])
