@@ -129,6 +129,8 @@ def main():
     h, w, c = HEIGHT // 8, WIDTH // 8, 128
     L, n = h * w, (h // 2) * (w // 2)
     attn_flops = 4.0 * (2 * b) * L * n * c                          # QK^T + PV per launch
+    if getattr(model.ops, 'fused_merge', False):
+        attn_flops += 2.0 * (2 * b) * L * c * c                     # + the merge Linear folded into the epilogue
     gsv_flops = b * (2.0 * L * L * c + 4.0 * L * L)                 # per launch (corr or propagation)
     issued = 3.0 if args.precision == 'exact' else 1.0
     # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be

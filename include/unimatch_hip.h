@@ -95,6 +95,16 @@ int um_window_attn_planes_fwd(const void* q_planes, const void* k_planes, const 
                               long q_plane_stride, long kv_plane_stride,
                               int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, void* stream);
 
+/* um_window_attn_planes_fwd with the layer's tail folded into the epilogue (unimatch/transformer.py:137-138, 144):
+ *     out = LayerNorm(attention . Wm^T; gamma, beta, eps) (+ residual)
+ * wm_planes: um_weight_planes() of the merge weight [128,128] with `wshift`; residual: optional fp32 [streams*h*w][128]
+ * (the self-attention layers' `source + message`).  The attention output never reaches HBM. */
+int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const void* v_planes, const void* wm_planes,
+                             const float* gamma, const float* beta, const float* residual, float eps, int wshift, float* out,
+                             int streams, int h, int w, int channels, int ldq, int ldkv, long q_plane_stride,
+                             long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode,
+                             void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Transformer-layer linears  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear without bias) on MFMA with fused
  * prologue / epilogue.  Replaces, per layer of unimatch/transformer.py: q/k/v projections (:58-60), merge +

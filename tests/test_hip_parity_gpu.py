@@ -548,6 +548,7 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         o0, o1 = proto(ops, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
         two = HipOps('exact')
         two.fused_ffn = False                     # the two-launch FFN stays covered
+        two.fused_merge = False                   # ... and merge + LayerNorm as its own launch
         t0, _ = proto(two, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
         assert err(o0, t0)[0] < 2e-4, tag
         want0, want1 = hp.feature_transformer(f0.double(), f1.double(), {kk: v.double() for kk, v in sd.items()},

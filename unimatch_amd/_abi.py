@@ -23,6 +23,8 @@ SIGNATURES = {
     'um_window_attn_workspace_bytes': (_c_size_t, [_c_int] * 4),
     'um_window_attn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_window_attn_planes_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [ctypes.c_long] * 2 + [_c_int] * 6 + [_c_void_p]),
+    'um_window_attn_merge_fwd': (_c_int, [_c_void_p] * 7 + [ctypes.c_float, _c_int, _c_void_p] + [_c_int] * 6 + [ctypes.c_long] * 2 +
+                                 [_c_int] * 6 + [_c_void_p]),
     'um_planes_bytes': (_c_size_t, [ctypes.c_long, _c_int, _c_int]),
     'um_weight_planes': (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p]),
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),

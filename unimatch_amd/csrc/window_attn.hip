@@ -51,6 +51,13 @@ struct WattnArgs {
     int total;                   // workgroups
     float scale_log2;            // log2(e) / sqrt(C)
     float mask_raw;              // -100 * sqrt(C): the shifted-window mask in raw q.k units
+    // MERGE variant: out = LayerNorm(attention . Wm^T) (+ residual)   (transformer.py:137-138, 144)
+    const unsigned short* wm;    // planes [NS][128][128] of the merge weight, pre-scaled by 2^wshift
+    long wm_plane_stride;
+    const float* gamma;
+    const float* beta;
+    const float* residual;       // optional [S][L][128]
+    float wm_scale, eps;         // 2^-wshift
 };
 
 // window-local token -> global token index and its mask class.
@@ -83,7 +90,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
                  : "memory");
 }
 
-template <class T, int NS>
+template <class T, int NS, bool MERGE>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
@@ -430,14 +437,124 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         lt = u + v2;
     }
     const float inv = 1.0f / lt;
-    if (tq < a.n) {
-        float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
+    if (!MERGE) {
+        if (tq < a.n) {
+            float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                    *reinterpret_cast<f32x4*>(ob + 32 * dt + 8 * g) = v;
+                }
+        }
+        return;
+    }
+    // ---- MERGE: out = LayerNorm(message . Wm^T) (+ residual), message = O / l still in the accumulators -------------------
+    // O^T goes accumulator -> operand exactly like P^T (k-step ks of 16 channels = registers 8 (ks & 1) .. +7 of tile ks >> 1);
+    // Wm (planes [NS][128][128]) is pulled into the now idle K/V ring by LDS-DMA with the K tile's swizzle while the
+    // fragments are being converted; Y^T = Wm . O^T keeps lane = query, so the LayerNorm statistics are in-lane sums plus
+    // one exchange with lane ^ 32.
+    {
+        const int row4 = lane >> 4, pc = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (8 * wave + i) + row4;             // wave w stages rows 32 w .. 32 w + 31
+            const int c = pc ^ (row & 15);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * c, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
+        }
+    }
+    i16x8 of[NS][8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int dt = ks >> 1, r0 = 8 * (ks & 1);
+        unsigned wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p0 = o[dt][r0 + 2 * j] * inv, p1 = o[dt][r0 + 2 * j + 1] * inv;
+            wh[j] = T::pack2(p0, p1);
+            if (NS == 2) {
+                const f32x2 hh = T::unpack2(wh[j]);
+                wl[j] = T::pack2(p0 - hh[0], p1 - hh[1]);
+            }
+        }
+        {
+            const auto x = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
+            const u32x4 f = {x[0], y[0], x[1], y[1]};
+            of[0][ks] = __builtin_bit_cast(i16x8, f);
+        }
+        if (NS == 2) {
+            const auto x = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
+            const u32x4 f = {x[0], y[0], x[1], y[1]};
+            of[NS - 1][ks] = __builtin_bit_cast(i16x8, f);
+        }
+    }
+    f32x16 yv[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[ot][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const i16x8 wh = *reinterpret_cast<const i16x8*>(lds + ot * (32 * 256) + koff[ks]);
+                if (NS == 2) {
+                    const i16x8 wl = *reinterpret_cast<const i16x8*>(lds + 32768 + ot * (32 * 256) + koff[ks]);
+                    yv[ot] = T::mfma(wl, of[0][ks], yv[ot]);
+                    yv[ot] = T::mfma(wh, of[NS - 1][ks], yv[ot]);
+                }
+                yv[ot] = T::mfma(wh, of[0][ks], yv[ot]);
+            }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            yv[ot][r] *= a.wm_scale;
+            s1 += yv[ot][r];
+        }
+    float u, v2;
+    half_wave_pair(s1, u, v2);
+    const float mean = (u + v2) * (1.0f / 128.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = yv[ot][r] - mean;
+            s2 = __builtin_fmaf(d, d, s2);
+        }
+    half_wave_pair(s2, u, v2);
+    const float rstd = 1.0f / sqrtf((u + v2) * (1.0f / 128.0f) + a.eps);
+    if (tq < a.n) {
+        // lane holds, for its query, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot)
+        float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
+        const float* rb = a.residual ? a.residual + (sbase + tokq) * UM_CHANNELS + 4 * half : nullptr;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(ob + 32 * dt + 8 * g) = v;
+                const int n = 32 * ot + 8 * g;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + n + 4 * half);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + n + 4 * half);
+                f32x4 y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (yv[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i];
+                if (rb) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rb + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += rr[i];
+                }
+                *reinterpret_cast<f32x4*>(ob + n) = y;
             }
     }
 }
@@ -456,7 +573,9 @@ extern "C" int um_debug_set_trace(void* ptr) {
 
 static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
-                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream);
+                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
+                              const unsigned short* wm = nullptr, const float* gamma = nullptr, const float* beta = nullptr,
+                              const float* residual = nullptr, float eps = 0.f, int wshift = 0);
 
 static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
                                int mode) {
@@ -503,6 +622,25 @@ extern "C" int um_window_attn_planes_fwd(const void* qp, const void* kp, const v
                               kv_rotate, mode, (hipStream_t)stream);
 }
 
+extern "C" int um_window_attn_merge_fwd(const void* qp, const void* kp, const void* vp, const void* wm_planes, const float* gamma,
+                                        const float* beta, const float* residual, float eps, int wshift, float* out, int streams,
+                                        int h, int w, int channels, int ldq, int ldkv, long q_plane_stride,
+                                        long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate,
+                                        int mode, void* stream) {
+    if (!qp || !kp || !vp || !out || !wm_planes || !gamma || !beta || wshift < 0 || wshift > 14) {
+        um_set_error("um_window_attn_merge_fwd: null pointer or bad wshift");
+        return -1;
+    }
+    if (int e = check_attn_geometry(streams, h, w, channels, win_h, win_w, shift_h, shift_w, mode)) return e;
+    if (ldq < UM_CHANNELS || ldkv < UM_CHANNELS || ldq % 8 || ldkv % 8) {
+        um_set_error("row strides ldq=%d ldkv=%d must be multiples of 8 and >= %d", ldq, ldkv, UM_CHANNELS);
+        return -1;
+    }
+    return launch_window_attn((const unsigned short*)qp, (const unsigned short*)kp, (const unsigned short*)vp, out, streams, h, w,
+                              ldq, ldkv, q_plane_stride, kv_plane_stride, win_h, win_w, shift_h, shift_w, kv_rotate, mode,
+                              (hipStream_t)stream, (const unsigned short*)wm_planes, gamma, beta, residual, eps, wshift);
+}
+
 extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
     if (streams <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
     return 3 * align256w(planes_bytes((long)streams * tokens, mode));
@@ -539,8 +677,17 @@ extern "C" int um_window_attn_fwd(const float* q, const float* k, const float* v
 
 static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
-                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream) {
+                              int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
+                              const unsigned short* wm, const float* gamma, const float* beta, const float* residual,
+                              float eps, int wshift) {
     WattnArgs a;
+    a.wm = wm;
+    a.wm_plane_stride = (long)UM_CHANNELS * UM_CHANNELS;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.residual = residual;
+    a.eps = eps;
+    a.wm_scale = ldexpf(1.f, -wshift);
     a.streams = streams;
     a.kv_rotate = ((kv_rotate % streams) + streams) % streams;
     a.qp = pq;
@@ -565,9 +712,14 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.scale_log2 = UM_LOG2E / sqrtf((float)UM_CHANNELS);
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
-    if (mode == 0)
-        hipLaunchKernelGGL((window_attn_kernel<Fp16, 2>), dim3(a.total), dim3(256), 0, stream, a);
+    if (wm) {
+        if (mode == 0)
+            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true>), dim3(a.total), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true>), dim3(a.total), dim3(256), 0, stream, a);
+    } else if (mode == 0)
+        hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, false>), dim3(a.total), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL((window_attn_kernel<Bf16, 1>), dim3(a.total), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, false>), dim3(a.total), dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }

@@ -134,10 +134,17 @@ class TransformerLayer(nn.Module):
             qp, _, _ = ops.linear_planes(src, (self.q_proj.weight,))
             kv, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
             q, k, v = (qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c)
-        att = ops.window_attention_planes(q, k, v, s, h, w, *geom, kv_rotate=kv_rotate).reshape(m, c)
-        if self.no_ffn:
-            return ops.linear_ln(att, (self.merge.weight,), self.norm1, residual=src).reshape(s, l, c)
-        msg = ops.linear_ln(att, (self.merge.weight,), self.norm1)
+        if getattr(ops, 'fused_merge', False):      # merge + LayerNorm (+ residual) inside the attention kernel
+            res = src if self.no_ffn else None
+            msg = ops.window_attention_merge(q, k, v, s, h, w, *geom, kv_rotate, self.merge.weight, self.norm1, res)
+            if self.no_ffn:
+                return msg
+            msg = msg.reshape(m, c)
+        else:
+            att = ops.window_attention_planes(q, k, v, s, h, w, *geom, kv_rotate=kv_rotate).reshape(m, c)
+            if self.no_ffn:
+                return ops.linear_ln(att, (self.merge.weight,), self.norm1, residual=src).reshape(s, l, c)
+            msg = ops.linear_ln(att, (self.merge.weight,), self.norm1)
         if getattr(ops, 'fused_ffn', False):      # one kernel, the [M, 8C] hidden activations never reach HBM
             return ops.ffn_ln(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2).reshape(s, l, c)
         hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)

@@ -6,6 +6,7 @@ the HIP kernels on torch's current stream through ``ctypes``.  Feature tensors a
 ``[N, L, C]`` fp32 (C = 128); flow-like tensors are ``[N, V, h, w]`` fp32 as in the reference.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -59,6 +60,8 @@ class HipOps:
 
     fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
+    fused_merge = os.environ.get('UM_NO_MERGE') != '1'   # merge + LayerNorm (+ residual) in the attention kernel's epilogue
+                                                         # (um_window_attn_merge_fwd); the env switch is for A/B timing
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
     WSHIFT = 10                # weights are scaled by 2^10 before the fp16 split (exact), see linear.hip
@@ -217,6 +220,27 @@ class HipOps:
             _ptr(qt) + 2 * qoff, _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(out), streams, h, w, 128,
             qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
         _abi.check(code, 'um_window_attn_planes_fwd')
+        return out
+
+    def window_attention_merge(self, q, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate, merge_weight, norm,
+                               residual=None):
+        """Attention on operand planes with ``LayerNorm(message . Wm^T) (+ residual)`` folded into the kernel's epilogue
+        (``um_window_attn_merge_fwd``); arguments as :meth:`window_attention_planes`."""
+        (qt, qrows, qcols, qoff), (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = q, k, v
+        if (krows, kcols) != (vrows, vcols) or qrows != streams * h * w or krows != qrows:
+            raise ValueError('inconsistent plane shapes')
+        wp, n, kk = self.weight_planes((merge_weight,))
+        if (n, kk) != (128, 128):
+            raise ValueError('window_attention_merge: the merge weight must be [128, 128]')
+        if residual is not None:
+            self._check_rows('residual', residual, 128)
+        out = torch.empty((streams, h * w, 128), dtype=torch.float32, device=qt.device)
+        meta = {'flops': 4.0 * streams * h * w * win_h * win_w * 128}
+        code = self._launch('window_attn', lambda: self.lib.um_window_attn_merge_fwd(
+            _ptr(qt) + 2 * qoff, _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(wp), _ptr(norm.weight), _ptr(norm.bias),
+            _ptr(residual) if residual is not None else None, float(norm.eps), self.WSHIFT, _ptr(out), streams, h, w, 128,
+            qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
+        _abi.check(code, 'um_window_attn_merge_fwd')
         return out
 
     # ------------------------------------------------------------------ convex upsampling (SURVEY 8(f) "next" row)
