@@ -137,6 +137,10 @@ def main():
         flow = torch.randn(B, 2, h, w, device=dev, generator=g) * 3
         run('cost volume cfg4 B=4 128x192 r=4', lambda: ops.local_corr_with_flow(f0, f1, flow, h, w, 4),
             2.0 * B * L * 100 * C, lib, iters, 'cost_volume')
+        yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
+        smooth = torch.stack([6.3 * torch.sin(yy / 23.0) + 0.01 * xx, 4.1 * torch.cos(xx / 31.0)], 0)[None].repeat(B, 1, 1, 1).contiguous()
+        run('cost volume, smooth flow (4-pixel blocking)', lambda: ops.local_corr_with_flow(f0, f1, smooth, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume')
         run('local corr softmax cfg4 B=4 128x192 r=4', lambda: ops.local_corr_softmax(f0, f1, h, w, 4),
             2.0 * B * L * 81 * C, lib, iters, 'local_corr')
         run('prop local cfg4 B=4 128x192 r=1', lambda: ops.prop_local(f0, f1, flow, h, w, 1),

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
                                                                    int radius, unsigned short* __restrict__ planes,
                                                                    long plane_stride, int ld) {
     __shared__ float dots_s[4][K4_MAX_DOTS + 4];
+    __shared__ float dots4_s[4][4][K4_MAX_DOTS + 4];
     __shared__ float tile_s[4][K4_MAX_TAPS][K4_PIX + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane >> 2, quarter = lane & 3;
@@ -156,7 +157,95 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
     const long nblocks = (total + K4_PIX - 1) / K4_PIX;
     for (long pb = (long)blockIdx.x * 4 + wave; pb < nblocks; pb += (long)gridDim.x * 4) {
         const long p0 = pb * K4_PIX;
-        for (int j = 0; j < K4_PIX; ++j) {
+        // Four consecutive pixels at a time: their (2r+2)^2 integer neighbourhoods overlap almost completely when the flow
+        // is locally smooth, and the kernel is bound by the L2 -> CU traffic of those neighbour rows (51 KB per pixel), so
+        // every neighbour row inside the group's bounding box is fetched ONCE and dotted with all four f0 vectors it
+        // belongs to (~3x fewer bytes).  The dot products themselves are unchanged (same order of operations).  Groups
+        // whose windows do not overlap enough (motion boundaries, row ends) take the one-pixel-at-a-time path.
+        for (int j0 = 0; j0 < K4_PIX; j0 += 4) {
+            if (p0 + j0 >= total) break;
+            int gb[4], gbx[4], gby[4];
+            float gwx[4], gwy[4];
+            bool gok[4];
+            int ux0 = 1 << 30, ux1 = -(1 << 30), uy0 = 1 << 30, uy1 = -(1 << 30);
+            bool same_image = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long pid = p0 + j0 + i;
+                gok[i] = pid < total;
+                const long pc = gok[i] ? pid : p0 + j0;
+                const int b = (int)(pc / L), p = (int)(pc - (long)b * L);
+                const int y = p / w, x = p - y * w;
+                const float px = (float)x + flow[((long)b * 2 + 0) * L + p];
+                const float py = (float)y + flow[((long)b * 2 + 1) * L + p];
+                const float fbx = floorf(px), fby = floorf(py);
+                gwx[i] = px - fbx;
+                gwy[i] = py - fby;
+                // clamp far-away bases so the int conversion is defined; such samples are all-zero anyway
+                gbx[i] = (int)fminf(fmaxf(fbx, -32768.f), 32768.f);
+                gby[i] = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
+                gb[i] = b;
+                if (gok[i]) {
+                    ux0 = min(ux0, gbx[i] - radius);
+                    ux1 = max(ux1, gbx[i] - radius + n1 - 1);
+                    uy0 = min(uy0, gby[i] - radius);
+                    uy1 = max(uy1, gby[i] - radius + n1 - 1);
+                    same_image = same_image && b == gb[0];
+                }
+            }
+            const int nw = ux1 - ux0 + 1, nh = uy1 - uy0 + 1;
+            const bool blocked = same_image && nw > 0 && nh > 0 && (long)nw * nh <= 2 * ndots;   // <= half the separate loads
+            if (blocked) {
+                f32x4 a4[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) load32(a4[i], f0 + (gok[i] ? p0 + j0 + i : p0 + j0) * UM_CHANNELS + 32 * quarter);
+                const int ncand = nw * nh;
+                const float* f1b = f1 + ((long)gb[0] * L) * UM_CHANNELS + 32 * quarter;
+                for (int r = 0; r * 16 < ncand; ++r) {
+                    const int t = r * 16 + slot;
+                    const int cy = t / nw, cx = t - cy * nw;
+                    const int yy = uy0 + cy, xx = ux0 + cx;
+                    const bool ok = t < ncand && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                    f32x4 bv[8];
+                    if (ok) load32(bv, f1b + (long)(yy * w + xx) * UM_CHANNELS);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ix = xx - (gbx[i] - radius), iy = yy - (gby[i] - radius);
+                        const bool mine = t < ncand && gok[i] && (unsigned)ix < (unsigned)n1 && (unsigned)iy < (unsigned)n1;
+                        float d = 0.f;
+                        if (ok && mine) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                d = __builtin_fmaf(a4[i][q][0], bv[q][0], d);
+                                d = __builtin_fmaf(a4[i][q][1], bv[q][1], d);
+                                d = __builtin_fmaf(a4[i][q][2], bv[q][2], d);
+                                d = __builtin_fmaf(a4[i][q][3], bv[q][3], d);
+                            }
+                        }
+                        d = quad_sum(d);
+                        if (quarter == 0 && mine) dots4_s[wave][i][iy * n1 + ix] = d;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!gok[i]) continue;
+                    const float wx = gwx[i], wy = gwy[i];
+                    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy);
+                    const float w10 = (1.f - wx) * wy, w11 = wx * wy;
+                    for (int k = lane; k < ntaps; k += 64) {
+                        const int ty = k / kw, tx = k - ty * kw;
+                        const float* dd = &dots4_s[wave][i][ty * n1 + tx];
+                        const float v = w00 * dd[0] + w01 * dd[1] + w10 * dd[n1] + w11 * dd[n1 + 1];
+                        tile_s[wave][k][j0 + i] = v * scale;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        for (int j = j0; j < j0 + 4; ++j) {
             const long pid = p0 + j;
             if (pid >= total) break;
             const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
@@ -193,6 +282,7 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        }   // groups of four pixels
         if (planes) {
             // channels-last operand planes for um_conv2d_ex (the motion encoder's 1x1 convolution reads them directly: the
             // [B, taps, h, w] fp32 volume never exists): pixel row = ld channels, taps first, zeros up to ld
