@@ -1,12 +1,12 @@
 """Diagnostic (GPU box): per-stage error of the product forward against an fp64 evaluation of the oracle,
-next to the fp32 CPU oracle's own error -- shows which stage (MIOpen convs, hipBLASLt linears, HIP kernels)
-adds noise beyond the fp32 floor.   python tools/stage_error.py [H W]"""
+next to the fp32 CPU oracle's own error -- shows which stage (encoder, Transformer, matching)
+adds noise beyond the fp32 floor.   python tests/diagnostics/stage_error.py [H W]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import model as om  # noqa: E402
 from unimatch_amd import UniMatch  # noqa: E402
