@@ -421,6 +421,66 @@ def test_conv2d_nhwc_matches_fp64(ops, case):
     assert err(got, want)[0] < 3e-6 * max(1.0, want.abs().max().item())
 
 
+def test_cost_volume_planes_equal_the_volume(ops):
+    """um_local_corr_with_flow_planes writes the same numbers as um_local_corr_with_flow, channels-last, as fp16 hi + lo
+    planes with zero padding channels and an untouched zero row (smooth flow -> four-pixel blocked path, noisy flow ->
+    pixel-by-pixel path)."""
+    b, h, w = 2, 14, 22
+    f0, f1 = rnd(120, b, h * w, 128).to(DEV), rnd(121, b, h * w, 128).to(DEV)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    smooth = torch.stack([2.3 * torch.sin(yy / 5.0) + 0.05 * xx, 1.7 * torch.cos(xx / 7.0)], 0)[None].repeat(b, 1, 1, 1)
+    for flow in (smooth.float().contiguous(), rnd(122, b, 2, h, w, scale=3.0)):
+        vol = ops.local_corr_with_flow(f0, f1, flow.to(DEV), h, w, 4)                       # [b, 81, h, w]
+        rows = b * h * w
+        buf = ops.planes_buffer(rows, 96)
+        ops.local_corr_with_flow_planes(f0, f1, flow.to(DEV), h, w, 4, buf, 96)
+        pl = buf.view(torch.float16).view(2, rows + 1, 96).float()
+        got = pl.sum(0)[:rows, :81].view(b, h, w, 81).permute(0, 3, 1, 2)
+        assert (got - vol).abs().max().item() < 2e-6 * max(1.0, vol.abs().max().item())
+        assert torch.equal(pl[:, :rows, 81:], torch.zeros(2, rows, 15, device=DEV))
+        assert torch.equal(pl[:, rows], torch.zeros(2, 96, device=DEV))
+
+
+def test_conv_ex_offsets_and_gates(ops):
+    """um_conv2d_ex reading a column slice and writing planes at a column offset (the block's concat-free chaining), and
+    the three um_nhwc_gate modes against plain tensor arithmetic."""
+    b, h, w, cin, cout = 2, 9, 11, 64, 128
+    rows = b * h * w
+    x = rnd(123, rows, 96)                                                       # the conv reads columns 32..96 of this
+    wt = rnd(124, cout, cin, 3, 3, scale=0.05)
+    bs = rnd(125, cout)
+    src = ops.planes_buffer(rows, 96)
+    ops.nhwc_gate(0, x.to(DEV), src, 96, 0, rows, 96)
+    dst = ops.planes_buffer(rows, 256)
+    f32 = torch.zeros((rows, 160), dtype=torch.float32, device=DEV)
+    wb = (ops.conv_weight_planes_from(wt.to(DEV)), bs.to(DEV))
+    ops.conv_ex((src, 96, 32, cin), (b, h, w), wb, (3, 3), 1, (1, 1), 3, out=(f32, 160, 32), outp=(dst, 256, 128))
+    xin = x[:, 32:].view(b, h, w, cin).permute(0, 3, 1, 2).double()
+    want = torch.tanh(torch.nn.functional.conv2d(xin, wt.double(), bs.double(), padding=1)).permute(0, 2, 3, 1).reshape(rows, cout)
+    assert err(f32[:, 32:], want)[0] < 3e-6
+    assert torch.equal(f32[:, :32], torch.zeros(rows, 32, device=DEV))                       # untouched columns
+    pl = dst.view(torch.float16).view(2, rows + 1, 256).float().sum(0)
+    assert err(pl[:rows, 128:], want)[0] < 3e-6 and torch.equal(pl[:rows, :128], torch.zeros(rows, 128, device=DEV))
+    # gates: r * h and the state update
+    zr = torch.sigmoid(rnd(126, rows, 256)).to(DEV)
+    hb = rnd(127, rows, 128).to(DEV)
+    q = torch.tanh(rnd(128, rows, 128)).to(DEV)
+    g = ops.planes_buffer(rows, 512)
+    ops.nhwc_gate(1, None, g, 512, 384, rows, 128, zr=zr, hbuf=hb)
+    got = g.view(torch.float16).view(2, rows + 1, 512).float().sum(0)[:rows, 384:]
+    assert (got - zr[:, 128:] * hb).abs().max().item() < 1e-6
+    want_h = (1 - zr[:, :128]) * hb + zr[:, :128] * q
+    ops.nhwc_gate(2, q, g, 512, 0, rows, 128, zr=zr, hbuf=hb)
+    assert (hb - want_h).abs().max().item() < 1e-6
+    got = g.view(torch.float16).view(2, rows + 1, 512).float().sum(0)[:rows, :128]
+    assert (got - hb).abs().max().item() < 1e-6
+    # ragged column scatter (flow: 2 channels at an even offset)
+    fl = rnd(129, rows, 2).to(DEV)
+    ops.nhwc_gate(0, fl, g, 512, 382, rows, 2)
+    got = g.view(torch.float16).view(2, rows + 1, 512).float().sum(0)[:rows, 382:384]
+    assert (got - fl).abs().max().item() < 1e-6
+
+
 def test_flow_warp(ops):
     """um_flow_warp against the oracle's grid_sample warp in fp64: sub-pixel offsets, samples leaving the image on every
     side (zeros padding), exact integer offsets."""
