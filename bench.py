@@ -136,11 +136,12 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes (they cannot be
     # read from inside this process); the corrected per-launch figure for this exact launch shape is kept in
     # profiles/ (see the note inside the file) and quoted here when the shape matches.
-    traffic = None
+    traffic = gsv_traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_window_attn_gsv.json')))
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_final.json')))
         if b == BATCH and args.precision == 'exact':
-            traffic = round(pm['window_attn_kernel<Fp16,2>']['hbm_traffic_bytes_per_launch'] / 1e6, 1)
+            traffic = round(pm['window_attn_kernel<Fp16, 2, true>']['hbm_traffic_bytes_per_launch'] / 1e6, 1)
+            gsv_traffic = round(pm['gsv_kernel<Fp16, 2, 2, false>']['hbm_traffic_bytes_per_launch'] / 1e6, 1)
     except (OSError, KeyError, ValueError):
         pass
     roof = None
@@ -149,7 +150,7 @@ def main():
         ach = attn_flops / dur
         roof = {'kernel': 'window_attn_kernel', 'bound': 'mfma', 'achieved': round(ach / 1e12, 2),
                 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4),
-                'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_window_attn_gsv.json)',
+                'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_final.json)',
                 'launches': attn_n, 'avg_launch_ms': round(attn_ms / attn_n, 4),
                 'algorithmic_gflop_per_launch': round(attn_flops / 1e9, 2),
                 'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4)}
@@ -159,7 +160,7 @@ def main():
         ach = gsv_flops / dur
         roof2 = {'kernel': 'gsv_kernel (global correlation / propagation)', 'bound': 'mfma',
                  'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': None, 'launches': gsv_n,
+                 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': gsv_traffic, 'launches': gsv_n,
                  'avg_launch_ms': round(gsv_ms / gsv_n, 4), 'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4)}
 
     # ---- CPU baseline: the pinned port of the reference, bounded sample, same workload shape
