@@ -159,6 +159,16 @@ int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_rows, const 
                  int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows, float* stats_out,
                  int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int act,
                  int wshift, int mode, void* stream);
+/* The two convolutions of a SepConvGRU half (unimatch/reg_refine.py:66-74) with the gate arithmetic in the epilogue.
+ *   gate 1: weights = [z ; r] stacked (2*channels outputs), sigmoid; z -> z_out [.][z_out_ld] (fp32), and r * hidden is written
+ *           as operand planes at (out_planes, outp_ld, outp_coff) -- the q convolution's input;
+ *   gate 2: weights = q (channels outputs), tanh; hidden <- (1 - z) * hidden + z * q in place (fp32 [.][channels], z = z[.][z_ld])
+ *           and as operand planes (the next convolution's input).
+ * Input slice / stride 1 / padding as um_conv2d_ex. */
+int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
+                      float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld, void* out_planes, int outp_ld,
+                      int outp_coff, long outp_rows, int batch, int hi, int wi, int cin, int channels, int kh, int kw, int pad_h,
+                      int pad_w, int wshift, int mode, void* stream);
 /* stats_out (optional, um_conv_stats_bytes() bytes, needs ho*wo % 128 == 0): per 128-pixel output tile the (mean, 0, sum of
  * squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
  * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */

@@ -34,6 +34,14 @@ struct ConvArgs {
     long outp_plane_stride;       //   convolution's input: no fp32 round trip, channel concatenation by offset)
     int out_ld, out_coff, outp_ld, outp_coff;
     int act;                      // 0 none, 1 ReLU, 2 sigmoid, 3 tanh
+    // SepConvGRU gate arithmetic in the epilogue (unimatch/reg_refine.py:66-74), after the activation:
+    //   gate 1 (z | r convolution, Cout = 2C): columns < C (z) go to `out` as usual; columns >= C (r) are multiplied by
+    //           gate_h[row][col - C] and written ONLY as planes at outp_coff + col - C          (r * h)
+    //   gate 2 (q convolution, Cout = C): v <- (1 - z) h + z v with z = gate_z[row][col], h = gate_h[row][col]; gate_h is
+    //           updated in place and v is written as planes (and to `out` if given)            (the new hidden state)
+    int gate, gate_c, gate_zld;
+    float* gate_h;
+    const float* gate_z;
     float* stats;                 // optional [M / 128][3][Cout]: per 128-pixel tile (mean, 0, sum of squared deviations)
     int B, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad_h, pad_w;
@@ -126,11 +134,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     for (int it = 0; it < ITER; ++it) {
         const int idx = it * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
         if (row0 + r < a.M && n0 + 4 * c < a.Cout) {
-            if (a.out) *reinterpret_cast<f32x4*>(a.out + (long)(row0 + r) * a.out_ld + a.out_coff + n0 + 4 * c) = d;
-            if (a.outp) {
-                unsigned short* dst = a.outp + (long)(row0 + r) * a.outp_ld + a.outp_coff + n0 + 4 * c;
+            const long row = row0 + r;
+            int col = n0 + 4 * c;
+            f32x4 d = d0;
+            bool to_out = a.out != nullptr, to_planes = a.outp != nullptr;
+            if (a.gate == 1) {
+                if (col >= a.gate_c) {
+                    col -= a.gate_c;
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(a.gate_h + row * a.gate_c + col);
+                    d = d * hv;
+                    to_out = false;
+                } else {
+                    to_planes = false;
+                }
+            } else if (a.gate == 2) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(a.gate_z + row * a.gate_zld + col);
+                float* hp = a.gate_h + row * a.gate_c + col;
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = (1.0f - z[i]) * hv[i] + z[i] * d[i];
+                *reinterpret_cast<f32x4*>(hp) = d;
+            }
+            if (to_out) *reinterpret_cast<f32x4*>(a.out + row * a.out_ld + a.out_coff + col) = d;
+            if (to_planes) {
+                unsigned short* dst = a.outp + row * a.outp_ld + a.outp_coff + col;
                 const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
                 *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
                 if (NS == 2) {
@@ -504,10 +533,11 @@ static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stre
     return hipGetLastError();
 }
 
-extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
-                            float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
-                            float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
-                            int pad_h, int pad_w, int act, int wshift, int mode, void* stream_) {
+static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
+                       float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
+                       float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
+                       int pad_h, int pad_w, int act, int wshift, int mode, void* stream_, int gate, float* gate_h,
+                       const float* gate_z, int gate_zld) {
     if (!a_planes || !w_planes || (!out && !out_planes) || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 ||
         cout <= 0 || cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) ||
         wshift < 0 || wshift > 14 || act < 0 || act > 3) {
@@ -523,7 +553,8 @@ extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_r
     const long rows_in = (long)batch * hi * wi, m = (long)batch * ho * wo;
     if (a_ld < a_coff + cin || a_ld % 8 != 0 || a_coff % 8 != 0 || a_rows < rows_in + 1 ||
         (out && (out_ld < out_coff + cout || out_ld % 4 != 0 || out_coff % 4 != 0)) ||
-        (out_planes && (outp_ld < outp_coff + cout || outp_ld % 4 != 0 || outp_coff % 4 != 0 || outp_rows < m))) {
+        (out_planes && (outp_ld < outp_coff + (gate == 1 ? cout / 2 : cout) || outp_ld % 4 != 0 || outp_coff % 4 != 0 ||
+                        outp_rows < m))) {
         um_set_error("um_conv2d: inconsistent leading dimensions / offsets / row counts");
         return -1;
     }
@@ -565,6 +596,11 @@ extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_r
     a.pad_w = pad_w;
     a.M = (int)m;
     a.act = act;
+    a.gate = gate;
+    a.gate_c = gate == 1 ? cout / 2 : cout;
+    a.gate_h = gate_h;
+    a.gate_z = gate_z;
+    a.gate_zld = gate_zld;
     a.out_scale = ldexpf(1.f, -wshift);
     hipError_t e;
     // widest output tile that does not waste more than a third of its columns
@@ -582,6 +618,33 @@ extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_r
         return (int)e;
     }
     return 0;
+}
+
+extern "C" int um_conv2d_ex(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
+                            float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
+                            float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
+                            int pad_h, int pad_w, int act, int wshift, int mode, void* stream_) {
+    return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, out, out_ld, out_coff, out_planes, outp_ld, outp_coff,
+                       outp_rows, stats_out, batch, hi, wi, cin, cout, kh, kw, stride, pad_h, pad_w, act, wshift, mode, stream_, 0,
+                       nullptr, nullptr, 0);
+}
+
+extern "C" int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes,
+                                 const float* bias, float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld,
+                                 void* out_planes, int outp_ld, int outp_coff, long outp_rows, int batch, int hi, int wi, int cin,
+                                 int channels, int kh, int kw, int pad_h, int pad_w, int wshift, int mode, void* stream_) {
+    if ((gate != 1 && gate != 2) || !hidden || !out_planes || channels <= 0 || channels % 4 != 0 || (gate == 1 && !z_out) ||
+        (gate == 2 && !z)) {
+        um_set_error("um_conv2d_gru_fwd: bad argument (gate=%d channels=%d)", gate, channels);
+        return -1;
+    }
+    if (gate == 1)       // z | r: sigmoid; z -> z_out[.][z_out_ld], r * hidden -> planes
+        return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, z_out, z_out_ld, 0, out_planes, outp_ld, outp_coff,
+                           outp_rows, nullptr, batch, hi, wi, cin, 2 * channels, kh, kw, 1, pad_h, pad_w, 2, wshift, mode, stream_,
+                           1, hidden, nullptr, 0);
+    // q: tanh; hidden <- (1 - z) hidden + z q, also written as planes
+    return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, nullptr, 0, 0, out_planes, outp_ld, outp_coff, outp_rows,
+                       nullptr, batch, hi, wi, cin, channels, kh, kw, 1, pad_h, pad_w, 3, wshift, mode, stream_, 2, hidden, z, z_ld);
 }
 
 extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,
@@ -713,6 +776,10 @@ extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, con
     a.pad_w = 0;
     a.M = (int)m;
     a.act = act;
+    a.gate = 0;
+    a.gate_c = a.gate_zld = 0;
+    a.gate_h = nullptr;
+    a.gate_z = nullptr;
     a.out_scale = ldexpf(1.f, -wshift);
     hipError_t e;
     if (cout % 128 == 0 || cout > 192) e = launch_conv<4>(a, 0, stream);

@@ -383,6 +383,25 @@ class HipOps:
             {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin})
         _abi.check(code, 'um_conv2d_ex')
 
+    def conv_gru(self, gate, src, geom, wb, ksize, pad, hidden, outp, z=None, z_out=None):
+        """``um_conv2d_gru_fwd``: gate 1 = (z | r) convolution -> ``z_out`` fp32 and ``r * hidden`` planes; gate 2 = q
+        convolution -> ``hidden`` updated in place and written as planes.  ``src`` / ``wb`` / ``outp`` as :meth:`conv_ex`."""
+        buf, a_ld, a_coff, cin = src
+        b, h, w = geom
+        (wp, cout, wcin, kh, kw), bias = wb
+        c = hidden.shape[1]
+        if wcin != cin or (kh, kw) != tuple(ksize) or cout != (2 * c if gate == 1 else c):
+            raise ValueError('conv_gru: weight / hidden shapes do not match')
+        p_t, p_ld, p_coff = outp
+        zt = z if gate == 2 else None
+        code = self._launch('conv', lambda: self.lib.um_conv2d_gru_fwd(
+            gate, _ptr(buf), a_ld, a_coff, buf.numel() // (4 * a_ld), _ptr(wp), _ptr(bias) if bias is not None else None,
+            _ptr(hidden), _ptr(zt) if zt is not None else None, zt.shape[1] if zt is not None else 0,
+            _ptr(z_out) if z_out is not None else None, z_out.shape[1] if z_out is not None else 0, _ptr(p_t), p_ld, p_coff,
+            p_t.numel() // (4 * p_ld), b, h, w, cin, c, kh, kw, pad[0], pad[1], self.WSHIFT, 0, _stream()),
+            {'flops': 2.0 * b * h * w * cout * kh * kw * cin})
+        _abi.check(code, 'um_conv2d_gru_fwd')
+
     def conv7(self, image, weight, bias, stride, act, out=None, outp=None):
         """7x7 / pad 3 convolution of an fp32 NCHW image with few channels (``um_conv7_fwd``), outputs as :meth:`conv_ex`."""
         b, c, h, w = image.shape

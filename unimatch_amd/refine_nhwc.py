@@ -12,7 +12,8 @@ what changes is the data flow:
       G   [512] = h (128) | inp (128) | motion (128 - fd) | flow (fd) | r * h (128)
   so ``hx = cat(h, x)`` is columns 0..384 of G and ``cat(r * h, x)`` is columns 128..512 read with the q-gate weight's input
   channels permuted to (x, r * h);
-* the z and r gates are one convolution (256 outputs, sigmoid epilogue);
+* the z and r gates are one convolution (256 outputs, sigmoid epilogue) whose epilogue also forms ``r * h``; the q
+  convolution's epilogue (tanh) performs the state update ``h <- (1 - z) h + z q`` (``um_conv2d_gru_fwd``);
 * the mask head only runs in the iteration whose mask is used (the reference computes and discards the others).
 """
 import torch
@@ -85,7 +86,6 @@ class NhwcUpdateBlock:
         ops.nhwc_gate(0, inp, self.G, 512, 128, rows, 128)
         self.H = torch.empty_like(self.net0)
         self.ZR = torch.empty((rows, 256), dtype=torch.float32, device=proj.device)
-        self.Q = torch.empty((rows, 128), dtype=torch.float32, device=proj.device)
         self.D = torch.empty((rows, 4), dtype=torch.float32, device=proj.device)
 
     def iterate(self, ori0, ori1, disp, flow, want_mask):
@@ -106,10 +106,9 @@ class NhwcUpdateBlock:
         self.H.copy_(self.net0)
         ops.nhwc_gate(0, self.H, self.G, 512, 0, rows, 128)
         for tag, ks, pad in (('1', (1, 5), (0, 2)), ('2', (5, 1), (2, 0))):
-            ops.conv_ex((self.G, 512, 0, 384), g, W['zr' + tag], ks, 1, pad, 2, out=(self.ZR, 256, 0))
-            ops.nhwc_gate(1, None, self.G, 512, 384, rows, 128, zr=self.ZR, hbuf=self.H)
-            ops.conv_ex((self.G, 512, 128, 384), g, W['q' + tag], ks, 1, pad, 3, out=(self.Q, 128, 0))
-            ops.nhwc_gate(2, self.Q, self.G, 512, 0, rows, 128, zr=self.ZR, hbuf=self.H)
+            # gate arithmetic in the convolutions' epilogues: (z | r) -> z (fp32) and r * h (planes); q -> h updated in place
+            ops.conv_gru(1, (self.G, 512, 0, 384), g, W['zr' + tag], ks, pad, self.H, (self.G, 512, 384), z_out=self.ZR)
+            ops.conv_gru(2, (self.G, 512, 128, 384), g, W['q' + tag], ks, pad, self.H, (self.G, 512, 0), z=self.ZR)
         # flow head (reg_refine.py:39-52)
         ops.conv_ex((self.G, 512, 0, 128), g, W['fh1'], (3, 3), 1, (1, 1), 1, outp=(self.FH, 256, 0))
         ops.conv_ex((self.FH, 256, 0, 256), g, W['fh2'], (3, 3), 1, (1, 1), 0, out=(self.D, 4, 0))
