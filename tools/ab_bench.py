@@ -1,29 +1,51 @@
-"""Diagnostic: same-process A/B of the full forward with individual fused kernels switched off (interleaved rounds)."""
-import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from unimatch_amd import UniMatch
-from unimatch_amd.ops import HipOps
-from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict
-ck, fk = CONFIGS['gmflow_s1']
-model = UniMatch(**ck).eval()
-model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}))
-model = model.cuda()
-i0, i1 = synth_images(8, 512, 768, seed=1000, kind='shift'); i0, i1 = i0.cuda(), i1.cuda()
-class Without:
-    """Proxy of a HipOps that hides some methods (the model then takes its stock PyTorch path for those)."""
-    def __init__(self, ops, hidden, **attrs):
-        self.__dict__.update(_ops=ops, _hidden=set(hidden), **attrs)
-    def __getattr__(self, k):
-        if k in self._hidden:
-            raise AttributeError(k)
-        return getattr(self._ops, k)
-base = HipOps('exact')
-variants = {'all fused': base, 'torch convex upsample': Without(base, ['convex_upsample'])}
-def run(ops, n=10):
-    model.bind_ops(ops)
-    for _ in range(2): model(i0, i1, **fk)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): model(i0, i1, **fk)
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
-for rnd in range(3):
-    print('  '.join(f'{k}: {run(v):.2f} ms' for k, v in variants.items()), flush=True)
+"""Same-box A/B of whole-model throughput (GPU box).
+
+MI355X boxes differ by +-5 % in `bench.py` throughput and a kernel's microbenchmark time is not its time inside the model
+(a kernel launched back to back runs hotter and therefore at a lower clock than the same kernel between memory-bound
+neighbours), so every optimisation of round 1 was accepted or dropped on an ABAB run of `bench.py` itself on ONE box:
+
+    python tools/ab_bench.py --steps 30  A=UM_NO_MERGE=1  B=
+    python tools/ab_bench.py  old=UM_LIB=unimatch_amd/_variants/libold.so  new=
+
+Every argument is `label=ENV1=v1,ENV2=v2` (empty = the tree as it is).  Useful switches: `UM_LIB` (an alternative build of
+the library, e.g. compiled with a -D flag into unimatch_amd/_variants/), `UM_NO_MERGE=1` (merge + LayerNorm as its own
+launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only).  Run-to-run repeatability on one box is ~0.1 %.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    args = sys.argv[1:]
+    steps = '30'
+    if '--steps' in args:
+        i = args.index('--steps')
+        steps = args[i + 1]
+        del args[i:i + 2]
+    variants = []
+    for a in args:
+        label, _, envs = a.partition('=')
+        env = dict(kv.split('=', 1) for kv in envs.split(',') if kv)
+        variants.append((label, env))
+    if len(variants) < 2:
+        sys.exit(__doc__)
+    for rep in range(2):
+        for label, extra in variants:
+            env = dict(os.environ)
+            env.update(extra)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--steps', steps],
+                                 capture_output=True, text=True, env=env, cwd=ROOT)
+            try:
+                d = json.loads(out.stdout.strip().splitlines()[-1])
+                print(f'{label:20s} {d["value"]:9.2f} pairs/s  {d["ms_per_step"]:8.3f} ms/step  '
+                      f'window_attn {d["roofline"]["avg_launch_ms"]:.4f} ms', flush=True)
+            except (IndexError, ValueError, KeyError):
+                print(f'{label:20s} FAILED\n{out.stderr[-800:]}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
