@@ -48,6 +48,9 @@ def parse():
 
 
 UM_K_COUNT = 12      # include/unimatch_hip.h
+# what a memory-free MFMA loop with pseudo-random operands sustains on an MI355X under its power limit
+# (tools/mfma_peak.py, profiles/r01_mfma_sustained_peak.txt); the data-sheet peak is only reached with constant operands
+SUSTAINED_MFMA = 1.72e15
 
 
 def collect(lib, kid):
@@ -168,7 +171,9 @@ def main():
                 'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_final.json)',
                 'launches': attn_n, 'avg_launch_ms': round(attn_ms / attn_n, 4),
                 'algorithmic_gflop_per_launch': round(attn_flops / 1e9, 2),
-                'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4)}
+                'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
+                'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
+                'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4)}
     roof2 = None
     if gsv_n:
         dur = gsv_ms / gsv_n * 1e-3

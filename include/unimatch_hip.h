@@ -64,6 +64,10 @@ const char* um_last_error_string(void);
 #define UM_K_FFN 10          /* ffn_kernel (um_ffn_fwd)                                                  */
 #define UM_K_CONV 11         /* conv_kernel (um_conv2d_fwd)                                              */
 #define UM_K_COUNT 12
+/* Diagnostic: a memory-free loop of independent 32x32x16 fp16 MFMAs on every CU (8 * iters MFMAs per wave, 1024 workgroups of
+ * 8 waves): the sustained matrix-pipe rate of this part under its power limit, with one constant operand value or with
+ * pseudo-random operands (data toggling costs clock).  sink: any device float. */
+int um_debug_mfma_peak(float* sink, int iters, int random_operands, void* stream);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 
