@@ -12,7 +12,7 @@
 #include "common.h"
 #include "planes.h"
 
-#define NHWC_CHUNK_ROWS 4096
+#define NHWC_CHUNK_ROWS 256
 
 // ---- pass 1: per-chunk shifted sums.  grid (chunks, B), block 256; thread = (row lane, channel quad) --------------
 __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* partial, int P, int C, int nchunk) {
