@@ -569,6 +569,47 @@ def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw):
     assert err(got, own)[0] < 1e-5
 
 
+def _random_conv_cases(n, seed=2024):
+    """Deterministic pseudo-random convolution geometries: every kernel family (generic / row-window, all tile widths),
+    odd sizes, ragged tiles, non-square kernels and paddings."""
+    import random
+    rng = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        kh, kw = rng.choice([(1, 1), (3, 3), (3, 3), (1, 5), (5, 1), (3, 1), (1, 3), (5, 5), (7, 7)])
+        stride = rng.choice([1, 1, 1, 2])
+        ph, pw = rng.choice([(kh // 2, kw // 2), (kh // 2, kw // 2), (0, 0), (kh // 2, 0), (1, 2)])
+        b, h, w = rng.choice([1, 2, 3]), rng.randint(5, 40), rng.randint(5, 40)
+        cin = rng.choice([32, 64, 96, 128, 160])
+        cout = rng.choice([4, 8, 36, 64, 96, 100, 128, 192, 256])
+        if (h + 2 * ph - kh) // stride + 1 < 1 or (w + 2 * pw - kw) // stride + 1 < 1:
+            continue
+        cases.append((b, cin, cout, h, w, kh, kw, stride, ph, pw, rng.random() < 0.5, rng.choice([0, 1, 2, 3])))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases(28))
+def test_conv2d_ex_random_geometries(ops, case):
+    """um_conv2d_ex over pseudo-random geometries (kernel shapes, strides, paddings, channel counts, activations) against
+    torch conv2d in fp64."""
+    b, cin, cout, h, w, kh, kw, stride, ph, pw, bias, act = case
+    x = rnd(130, b, cin, h, w, scale=1.2)
+    wt = rnd(131, cout, cin, kh, kw, scale=(2.0 / (cin * kh * kw)) ** 0.5)
+    bs = rnd(132, cout) if bias else None
+    pre = torch.nn.functional.conv2d(x.double(), wt.double(), bs.double() if bias else None, stride=stride, padding=(ph, pw))
+    want = (pre, pre.relu(), torch.sigmoid(pre), torch.tanh(pre))[act]
+    ho, wo = want.shape[-2:]
+    rows_in, rows_out = b * h * w, b * ho * wo
+    src = ops.planes_buffer(rows_in, cin)
+    ops.nhwc_gate(0, x.permute(0, 2, 3, 1).reshape(rows_in, cin).contiguous().to(DEV), src, cin, 0, rows_in, cin)
+    out = torch.empty((rows_out, cout), dtype=torch.float32, device=DEV)
+    wb = (ops.conv_weight_planes_from(wt.to(DEV)), bs.to(DEV) if bias else None)
+    ops.conv_ex((src, cin, 0, cin), (b, h, w), wb, (kh, kw), stride, (ph, pw), act, out=(out, cout, 0))
+    got = out.view(b, ho, wo, cout).permute(0, 3, 1, 2)
+    # fp32 accumulation over K = kh*kw*cin terms of 22-bit operand products; the activations have slope <= 1
+    assert err(got, want)[0] < 3e-6 * max(1.0, pre.abs().max().item()), case
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 37, 29), (1, 96, 64, 48), (3, 128, 5, 7)])
 def test_nhwc_instance_norm(ops, shape):
     """NHWC InstanceNorm (+ ReLU, + shortcut + ReLU) against fp64, both output formats; a large mean exercises the
