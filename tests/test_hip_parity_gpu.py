@@ -634,6 +634,40 @@ def test_nhwc_instance_norm(ops, shape):
         assert (pl[:, :rows].sum(0) - f32).abs().max().item() < 2e-6 * max(1.0, f32.abs().max().item())
 
 
+@pytest.mark.parametrize('shifted,residual', [(False, True), (True, False)])
+def test_attention_merge_and_kv_rotate(ops, shifted, residual):
+    """um_window_attn_merge_fwd with kv_rotate against its composition from separately tested pieces in fp64: attention of
+    stream s against the keys / values of stream (s + r) mod S, then merge Linear + LayerNorm (+ residual)."""
+    s_, h, w, c = 4, 16, 24, 128
+    l = h * w
+    x = rnd(140, s_ * l, c, scale=1.5)
+    xt = rnd(141, s_ * l, c, scale=1.5)
+    wq, wk, wv, wm = (rnd(142 + i, c, c, scale=0.09) for i in range(4))
+    norm = torch.nn.LayerNorm(c)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * rnd(146, c))
+        norm.bias.copy_(0.1 * rnd(147, c))
+    geom = (8, 12, 4, 6) if shifted else (8, 12, 0, 0)
+    rot = 2
+    # fp64 reference: explicit rotation of the key / value streams, oracle attention, merge, LayerNorm
+    q64 = (x.double() @ wq.double().t()).view(s_, l, c)
+    kv_src = xt.double().view(s_, l, c).roll(-rot, 0)                       # stream s reads stream (s + rot) mod S
+    k64, v64 = kv_src @ wk.double().t(), kv_src @ wv.double().t()
+    att = hp.window_attention(q64, k64, v64, h, w, *geom)
+    want = torch.nn.functional.layer_norm(att.reshape(s_ * l, c) @ wm.double().t(), (c,), norm.weight.double(),
+                                          norm.bias.double(), norm.eps)
+    if residual:
+        want = want + x.double()
+    norm = norm.to(DEV)
+    xd, xtd = x.to(DEV), xt.to(DEV)
+    qp, _, _ = ops.linear_planes(xd, (wq.to(DEV),))
+    kv, _, n2 = ops.linear_planes(xtd, (wk.to(DEV), wv.to(DEV)))
+    m = s_ * l
+    got = ops.window_attention_merge((qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, *geom, rot, wm.to(DEV), norm,
+                                     xd if residual else None)
+    assert err(got.reshape(m, c), want)[0] < 5e-5
+
+
 def test_fused_layer_matches_unfused_layer(ops, golden):
     """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
     g = golden('transformer')
