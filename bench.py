@@ -237,7 +237,7 @@ def main():
                    'per_gpu_batch': b, 'global_batch': world * b, 'precision': args.precision,
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; '
                                      'Transformer linears / LayerNorm / FFN, encoder and mask-head convolutions on the same split-fp16 MFMA '
-                                     'kernels (no MIOpen / hipBLASLt kernel in the forward)',
+                                     'kernels (no MIOpen kernel in the forward; two small hipBLASLt GEMMs remain: the propagation layer\'s Linear with bias)',
                    'parallelism': f'dp{world} (batch-sharded, all-gather of predictions)' if distributed else 'single GPU'},
         'roofline': roof, 'roofline_global_corr': roof2,
         'split_planes_ms_per_step': round(split_ms / args.steps, 3) if split_n else None,

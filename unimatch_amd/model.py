@@ -16,8 +16,8 @@ What is different inside:
     (``unimatch_amd.ops.HipOps``); no L x L, n x n or [B, L, C, taps] tensor is ever materialised;
   * inference only (the reference's training-mode extra outputs are out of scope).
   * the Transformer's linears / LayerNorm / FFN, the CNN encoder, the refinement block and the upsampler's mask head run
-    on the same library (split-fp16 MFMA GEMM / implicit-GEMM convolution kernels, channels-last): on a GPU no MIOpen /
-    hipBLASLt kernel is left in the flow and stereo forwards.
+    on the same library (split-fp16 MFMA GEMM / implicit-GEMM convolution kernels, channels-last): on a GPU no MIOpen kernel
+    is left in the flow and stereo forwards (hipBLASLt: only the propagation layer's two small Linears with bias).
 There is no CPU or PyTorch fallback for the hot path (the stock ``nn.Module`` convolution code only runs on CPU tensors).
 """
 import math
