@@ -606,8 +606,8 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     // widest output tile that does not waste more than a third of its columns
     const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
     // same-size stride-1 3-tap rows: the row-window kernel (its LDS budget allows 64- and 96-wide output tiles)
-    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && m >= 256 &&
-                      getenv("UM_CONV_NO_ROWS") == nullptr;
+    static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
+    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && m >= 256 && rows_enabled;
     if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
     else if (rows && nt == 3) e = launch_conv_rows<3, 3>(a, mode, (hipStream_t)stream_);
     else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
