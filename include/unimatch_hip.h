@@ -173,8 +173,8 @@ int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long
                       float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld, void* out_planes, int outp_ld,
                       int outp_coff, long outp_rows, int batch, int hi, int wi, int cin, int channels, int kh, int kw, int pad_h,
                       int pad_w, int wshift, int mode, void* stream);
-/* stats_out (optional, um_conv_stats_bytes() bytes, needs ho*wo % 128 == 0): per 128-pixel output tile the (mean, 0, sum of
- * squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
+/* stats_out (optional, um_conv_stats_bytes() bytes): per 128-pixel output tile of every image (the last one may be
+ * ragged) the (mean, 0, sum of squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
  * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */
 size_t um_conv_stats_bytes(int batch, int pixels, int channels);
 

@@ -550,21 +550,27 @@ def test_stem_conv_matches_fp64(ops, bhw, normalize):
     assert err(got, want)[0] < 4e-6 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize('cout,hw', [(64, (16, 24)), (96, (32, 12)), (256, (8, 16))])
-def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw):
+@pytest.mark.parametrize('cout,hw,stride', [(64, (16, 24), 1), (96, (32, 12), 1), (256, (8, 16), 1),
+                                            (64, (15, 21), 1),        # 315 pixels: ragged third tile (row-window kernel)
+                                            (128, (19, 23), 1),       # NT = 4: generic kernel, 437 pixels
+                                            (96, (7, 9), 1),          # 63 pixels: a single partial tile per image
+                                            (96, (21, 30), 2),        # stride 2 -> 11 x 15 = 165 pixels
+                                            (64, (47, 63), 2)])       # KITTI-like odd map
+def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw, stride):
     """um_conv2d_fwd(stats_out) -> um_nhwc_instance_norm(conv_stats): the per-tile statistics written by the convolution's
-    epilogue must give the same normalisation as the fp64 reference (and as the norm's own statistics pass)."""
+    epilogue must give the same normalisation as the fp64 reference (and as the norm's own statistics pass), for any
+    number of pixels per image (tiles are per image, the last one ragged)."""
     b, cin, (h, w) = 3, 64, hw
     x = rnd(96, b, cin, h, w, scale=1.5)
     wt = rnd(97, cout, cin, 3, 3, scale=0.06)
     bs = 3.0 * rnd(98, cout)                                   # a large mean per channel
     planes, _ = _nhwc_planes(ops, x)
-    y, ho, wo = ops.conv2d_nhwc((planes, b, h, w, cin), wt.to(DEV), bs.to(DEV), 1, (1, 1), stats=True)
+    y, ho, wo = ops.conv2d_nhwc((planes, b, h, w, cin), wt.to(DEV), bs.to(DEV), stride, (1, 1), stats=True)
     assert ops.last_conv_stats is not None
     _, got = ops.nhwc_norm(y, b, ho * wo, relu=False, want_planes=False, want_f32=True, conv_stats=ops.last_conv_stats)
     _, own = ops.nhwc_norm(y, b, ho * wo, relu=False, want_planes=False, want_f32=True)
     want = torch.nn.functional.instance_norm(
-        torch.nn.functional.conv2d(x.double(), wt.double(), bs.double(), padding=1))
+        torch.nn.functional.conv2d(x.double(), wt.double(), bs.double(), stride=stride, padding=1))
     assert err(got.view(b, ho, wo, cout).permute(0, 3, 1, 2), want)[0] < 3e-5
     assert err(got, own)[0] < 1e-5
 

@@ -1,4 +1,7 @@
-"""Run the five BASELINE.json configs at their full sizes on one GPU (diagnostic; bench.py measures configs[1])."""
+"""Run the five BASELINE.json configs at their full sizes on one GPU (diagnostic; bench.py measures configs[1]).
+
+    python tools/bench_configs.py [--only 1,5] [--steps 20]
+"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from unimatch_amd import UniMatch
@@ -10,7 +13,12 @@ RUNS = [  # (label, config, batch, H, W)
     ('cfg4 GMFlow-s2-rr6 4x512x768 (per-GPU share of B=32)', 'gmflow_s2_rr6', 4, 512, 768),
     ('cfg5 GMDepth-s1 16x480x640', 'gmdepth_s1', 16, 480, 640),
 ]
-for label, name, b, hh, ww in RUNS:
+ARGV = sys.argv[1:]
+ONLY = [int(v) for v in ARGV[ARGV.index('--only') + 1].split(',')] if '--only' in ARGV else [1, 2, 3, 4, 5]
+STEPS = int(ARGV[ARGV.index('--steps') + 1]) if '--steps' in ARGV else 5
+for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
+    if idx not in ONLY:
+        continue
     ck, fk = CONFIGS[name]
     model = UniMatch(**ck).eval()
     model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
@@ -24,7 +32,7 @@ for label, name, b, hh, ww in RUNS:
     for _ in range(2):
         out = model(i0, i1, **kw)['flow_preds'][0]
     torch.cuda.synchronize(); t = time.perf_counter()
-    n = 5
+    n = STEPS
     for _ in range(n):
         out = model(i0, i1, **kw)['flow_preds'][0]
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n

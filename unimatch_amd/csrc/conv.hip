@@ -59,11 +59,12 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
                  : "memory");
 }
 
-// ---- epilogue shared by both kernels: lane holds, for pixel m0 + 32*wave + (lane & 31), outputs n0 + 32*nt + 8*g + 4*half + i
-// (reg 4*g + i).  `scratch` = LDS beyond the (now idle) staging ring: 2 * 32 NT floats per wave for the statistics.
+// ---- epilogue shared by both kernels: lane holds, for pixel pl0 + 32*wave + (lane & 31) of image bt, outputs
+// n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i).  Output tiles never straddle images (the last tile of an image is ragged).  `scratch` = LDS beyond the (now idle) staging ring: 2 * 32 NT floats per wave for the statistics.
 template <typename T, int NS, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                              int m0, int n0, int tid, int wave, int lane, int half) {
+                                              int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
+    const int P = a.Ho * a.Wo;                                    // pixels per image
     // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
     // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
     constexpr int ROWB = 32 * NT * 4;                             // bytes per pixel row of the tile
@@ -90,38 +91,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     if (a.stats) {
         // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
         // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
-        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  Only used when tiles do not
-        // straddle images (pixels per image a multiple of 128), so every row is valid here.
+        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  nv = valid pixels of this wave
+        // (32 except in the ragged last tile of an image).
         float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT);
         for (int ch = lane; ch < 32 * NT; ch += 64) {
             const int c = ch >> 2, ci = ch & 3;
+            const int nv = min(32, max(0, P - (pl0 + 32 * wave)));
             const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) {
                 const float d = *reinterpret_cast<const float*>(stg + r * ROWB + ((c ^ (r & 7)) << 4) + ci * 4) - k;
-                s1 += d;
-                s2 = __builtin_fmaf(d, d, s2);
+                if (r < nv) {
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                }
             }
-            ws[ch] = k + s1 * (1.0f / 32.0f);                               // mean of the wave's 32 pixels
-            ws[32 * NT + ch] = s2 - s1 * s1 * (1.0f / 32.0f);              // sum of squared deviations
+            const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
+            ws[ch] = k + s1 * inv;                                          // mean of the wave's valid pixels
+            ws[32 * NT + ch] = s2 - s1 * s1 * inv;                          // sum of squared deviations
         }
         __syncthreads();
         // threads 0 .. 32 NT - 1 of every group of four waves merge that group's 128 pixels
         const int grp = tid >> 8, gt = tid & 255;
-        if (gt < 32 * NT && n0 + gt < a.Cout && m0 + 128 * grp < a.M) {
+        if (gt < 32 * NT && n0 + gt < a.Cout && pl0 + 128 * grp < P) {
             const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT);
             const int tid = gt;
-            float mean = w0[tid], m2 = w0[32 * NT + tid], n = 32.f;
+            float mean = w0[tid], m2 = w0[32 * NT + tid];
+            float n = (float)min(32, P - (pl0 + 128 * grp));                 // wave 0 of the group always has valid pixels
 #pragma unroll
             for (int wv = 1; wv < 4; ++wv) {
-                const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
-                const float delta = mw - mean, nn = n + 32.f;
-                mean += delta * (32.f / nn);
-                m2 += m2w + delta * delta * (n * 32.f / nn);
-                n = nn;
+                const float nw = (float)min(32, max(0, P - (pl0 + 128 * grp + 32 * wv)));
+                if (nw > 0.f) {
+                    const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
+                    const float delta = mw - mean, nn = n + nw;
+                    mean += delta * (nw / nn);
+                    m2 += m2w + delta * delta * (n * nw / nn);
+                    n = nn;
+                }
             }
-            float* pr = a.stats + ((long)(m0 / 128 + grp) * 3) * a.Cout + n0 + tid;
+            const int tiles128 = (P + 127) / 128;                           // statistics parts per image
+            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + n0 + tid;
             pr[0] = mean;
             pr[a.Cout] = 0.f;
             pr[2 * a.Cout] = m2;
@@ -129,14 +139,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     }
     constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
     constexpr int ITER = 32 * CPR / 64;
-    const int row0 = m0 + 32 * wave;
+    const int rloc0 = pl0 + 32 * wave;                            // first pixel of this wave inside the image
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int idx = it * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-        if (row0 + r < a.M && n0 + 4 * c < a.Cout) {
-            const long row = row0 + r;
+        if (rloc0 + r < P && n0 + 4 * c < a.Cout) {
+            const long row = (long)bt * P + rloc0 + r;
             int col = n0 + 4 * c;
             f32x4 d = d0;
             bool to_out = a.out != nullptr, to_planes = a.outp != nullptr;
@@ -184,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * (32 * NT);
+    const int P = a.Ho * a.Wo, tpi = (P + 127) / 128;            // pixels / 128-pixel tiles per image
+    const int bt = blockIdx.x / tpi, pl0 = (blockIdx.x - bt * tpi) * 128;
+    const int n0 = blockIdx.y * (32 * NT);
     const int cpt = a.Cin >> 5;                  // 32-channel chunks per tap
     const int nstage = a.KH * a.KW * cpt;
     const int ktot = a.KH * a.KW * a.Cin;
@@ -195,15 +207,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     bool pok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int p = m0 + 32 * wave + 16 * i + (lane >> 2);
-        pok[i] = p < a.M;
-        const int pp = pok[i] ? p : 0;
-        const int hw = a.Ho * a.Wo;
-        const int b = pp / hw, rem = pp - b * hw;
+        const int p = pl0 + 32 * wave + 16 * i + (lane >> 2);
+        pok[i] = p < P;
+        const int rem = pok[i] ? p : 0;
         const int y = rem / a.Wo, x = rem - y * a.Wo;
         py[i] = y * a.stride - a.pad_h;
         px[i] = x * a.stride - a.pad_w;
-        pbase[i] = b * a.Hi * a.Wi;
+        pbase[i] = bt * a.Hi * a.Wi;
     }
     const unsigned zero_row = a.zero_row;
     unsigned rowoff[2];                          // byte offset of the source row of the tap being staged
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, m0, n0, tid, wave, lane, half);
+    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
 }
 
 // ---- row-window variant: same-size stride-1 convolutions with KW > 1 horizontal taps ------------------------------------------
@@ -330,14 +340,15 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, fr = lane & 31;
-    const int m0 = blockIdx.x * 256, n0 = blockIdx.y * (32 * NT);
+    const int P = a.Ho * a.Wo, tpi = (P + 255) / 256;            // pixels / 256-pixel tiles per image
+    const int bt = blockIdx.x / tpi, pl0 = (blockIdx.x - bt * tpi) * 256;
+    const int n0 = blockIdx.y * (32 * NT);
     const int cpt = a.Cin >> 5;
     const int nstage = a.KH * cpt;
     const int ktot = a.KH * KW * a.Cin;
-    const int hw = a.Ho * a.Wo;
 
     // ---- window rows this lane stages: DMA block jr = wave + 8 i (16 rows each), row j = 16 jr + (lane >> 2) ----------------
-    // validity is decided by the row's "central" user, output pixel m0 + j - pw (see above)
+    // validity is decided by the row's "central" user, output pixel pl0 + j - pw of image bt (see above)
     const int dcp = lane & 3;
     int wy[3];
     long wflat[3];
@@ -345,12 +356,11 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = 16 * (wave + 8 * i) + (lane >> 2);
-        const long p = (long)m0 + j - a.pad_w;
-        wok[i] = (wave + 8 * i) < 17 && p >= 0 && p < a.M;
-        const long pp = wok[i] ? p : 0;
-        const int b = (int)(pp / hw), rem = (int)(pp - (long)b * hw);
+        const int p = pl0 + j - a.pad_w;
+        wok[i] = (wave + 8 * i) < 17 && p >= 0 && p < P;
+        const int rem = wok[i] ? p : 0;
         wy[i] = rem / a.Wo - a.pad_h;
-        wflat[i] = pp - (long)a.pad_h * a.Wi;
+        wflat[i] = (long)bt * P + rem - (long)a.pad_h * a.Wi;       // same-size convolution: input pixels = output pixels
     }
     unsigned rowoff[3];
     auto set_ky = [&](int ky) {
@@ -395,9 +405,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
     bool tap_ok[KW];
     bool any_masked = false;
     {
-        const long p = (long)m0 + 32 * wave + fr;
-        const bool pok = p < a.M;
-        const int x = (int)((pok ? p : 0) % a.Wo);
+        const int p = pl0 + 32 * wave + fr;
+        const bool pok = p < P;
+        const int x = (pok ? p : 0) % a.Wo;
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             tap_ok[kx] = pok && (unsigned)(x + kx - a.pad_w) < (unsigned)a.Wi;
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, m0, n0, tid, wave, lane, half);
+    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
 }
 
 template <int NS, int NT, int KW>
@@ -498,7 +508,7 @@ extern void um_set_error(const char* fmt, ...);
 
 template <int NT>
 static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
-    dim3 grid((a.M + 127) / 128, (a.Cout + 32 * NT - 1) / (32 * NT)), block(256);
+    dim3 grid(a.B * ((a.Ho * a.Wo + 127) / 128), (a.Cout + 32 * NT - 1) / (32 * NT)), block(256);
     ScopedKernelTimer timer(UM_K_CONV, stream);
     if (mode == 0)
         hipLaunchKernelGGL((conv_kernel<Fp16, 2, NT>), grid, block, 0, stream, a);
@@ -510,7 +520,7 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
 template <int NT, int KW>
 static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stream) {
     static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
-    dim3 grid((a.M + 255) / 256, (a.Cout + 32 * NT - 1) / (32 * NT)), block(512);
+    dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256), (a.Cout + 32 * NT - 1) / (32 * NT)), block(512);
     constexpr int LDS2 = ConvRowsLds<2, NT, KW>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW>::TOTAL;
     ScopedKernelTimer timer(UM_K_CONV, stream);
     if (mode == 0) {
@@ -558,8 +568,8 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
         um_set_error("um_conv2d: inconsistent leading dimensions / offsets / row counts");
         return -1;
     }
-    if (stats_out && (((long)ho * wo) % 128 != 0 || !out)) {
-        um_set_error("um_conv2d: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+    if (stats_out && !out) {
+        um_set_error("um_conv2d: fused statistics need the fp32 output");
         return -1;
     }
     if (a_rows * a_ld * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
@@ -607,7 +617,7 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
     // same-size stride-1 3-tap rows: the row-window kernel (its LDS budget allows 64- and 96-wide output tiles)
     static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
-    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && m >= 256 && rows_enabled;
+    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && (long)ho * wo >= 256 && rows_enabled;
     if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
     else if (rows && nt == 3) e = launch_conv_rows<3, 3>(a, mode, (hipStream_t)stream_);
     else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
@@ -725,8 +735,8 @@ extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, con
         um_set_error("um_conv7_fwd: inconsistent leading dimensions / offsets / row counts");
         return -1;
     }
-    if (stats_out && (((long)ho * wo) % 128 != 0 || !out)) {
-        um_set_error("um_conv7_fwd: fused statistics need ho * wo (= %d) to be a multiple of 128", ho * wo);
+    if (stats_out && !out) {
+        um_set_error("um_conv7_fwd: fused statistics need the fp32 output");
         return -1;
     }
     if ((rows + 8) * cpp * 2 >= (1L << 32) || m >= (1L << 31)) {

@@ -265,8 +265,8 @@ extern "C" size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channe
 }
 
 extern "C" size_t um_conv_stats_bytes(int batch, int pixels, int channels) {
-    if (batch <= 0 || pixels <= 0 || channels <= 0 || pixels % 128 != 0) return 0;
-    return (size_t)((long)batch * (pixels / 128) * 3 * channels) * sizeof(float);
+    if (batch <= 0 || pixels <= 0 || channels <= 0) return 0;
+    return (size_t)((long)batch * ((pixels + 127) / 128) * 3 * channels) * sizeof(float);
 }
 
 static bool nhwc_channels_ok(int c) { return c > 0 && c % 8 == 0 && c <= 256; }
@@ -292,12 +292,8 @@ extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void
         }
         stats = partial + (long)batch * nchunk * 3 * channels;
         if (conv_stats) {                                          // per-128-pixel tile statistics from um_conv2d_fwd
-            if (pixels % 128 != 0) {
-                um_set_error("um_nhwc_instance_norm: conv_stats need pixels %% 128 == 0");
-                return -1;
-            }
             hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, conv_stats, stats, pixels, channels,
-                               pixels / 128, 128, eps);
+                               (pixels + 127) / 128, 128, eps);
         } else {
             hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, partial, pixels, channels, nchunk);
             hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, partial, stats, pixels, channels,

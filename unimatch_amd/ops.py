@@ -304,8 +304,7 @@ class HipOps:
         return self._cache_put(key, (weight,), (planes, cout, cin, kh, kw))
 
     def conv2d_nhwc(self, act, weight, bias=None, stride=1, padding=(1, 1), relu=False, stats=False):
-        """``act``: ``(planes, b, h, w, cin)``; returns fp32 ``[b*ho*wo, cout]`` and ``(ho, wo)``.  With ``stats`` (and
-        ``ho*wo % 128 == 0``) the epilogue also emits the per-tile InstanceNorm statistics: ``self.last_conv_stats``."""
+        """``act``: ``(planes, b, h, w, cin)``; returns fp32 ``[b*ho*wo, cout]`` and ``(ho, wo)``.  With ``stats`` the epilogue also emits the per-tile InstanceNorm statistics: ``self.last_conv_stats``."""
         planes, b, h, w, cin = act
         wp, cout, wcin, kh, kw = self.conv_weight_planes(weight)
         if wcin != cin:
@@ -314,7 +313,7 @@ class HipOps:
         ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
         out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=planes.device)
         self.last_conv_stats = None
-        if stats and (ho * wo) % 128 == 0:
+        if stats:
             self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
                                                device=planes.device)
         st = self.last_conv_stats
@@ -468,7 +467,7 @@ class HipOps:
         scratch = torch.empty(self.lib.um_stem_planes_bytes(b, h, w), dtype=torch.uint8, device=image.device)
         out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=image.device)
         self.last_conv_stats = None
-        if stats and (ho * wo) % 128 == 0:
+        if stats:
             self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
                                                device=image.device)
         st = self.last_conv_stats
