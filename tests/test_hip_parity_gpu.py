@@ -403,6 +403,11 @@ def _nhwc_planes(ops, x_nchw):
     (1, 256, 128, 6, 10, 1, 5, 1, 0, 2, True, False),        # SepConvGRU horizontal
     (1, 256, 128, 10, 6, 5, 1, 1, 2, 0, True, False),        # SepConvGRU vertical
     (1, 32, 68, 5, 7, 7, 7, 1, 3, 3, True, False),           # 7x7, ragged cout
+    (1, 128, 128, 17, 19, 3, 3, 1, 1, 1, False, False),      # NT = 4 row window (16-channel stages), ragged second tile
+    (2, 128, 256, 16, 20, 3, 3, 1, 1, 1, True, True),        # NT = 4 row window, two output tiles, two images
+    (2, 256, 128, 18, 15, 1, 5, 1, 0, 2, True, False),       # GRU 1x5 gate shape: five-tap row window
+    (1, 256, 256, 9, 40, 1, 5, 1, 0, 2, True, False),        # GRU z|r shape, rows longer than the taps reach
+    (1, 64, 64, 33, 65, 3, 3, 1, 1, 1, True, True),          # NT = 2 row window, 9 tiles with a ragged tail
 ])
 def test_conv2d_nhwc_matches_fp64(ops, case):
     """um_conv2d_fwd (implicit GEMM on split-fp16 planes) against torch conv2d in fp64: every kernel geometry the

@@ -17,6 +17,7 @@
 // Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
 // computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "planes.h"
 
@@ -47,6 +48,7 @@ struct ConvArgs {
     int KH, KW, stride, pad_h, pad_w;
     int M;                        // B * Ho * Wo
     float out_scale;              // 2^-wshift
+    int xcd;                      // XCD-aware workgroup order (0: plain; A/B switch UM_CONV_NO_XCD)
 };
 
 __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -60,25 +62,28 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
 }
 
 // ---- epilogue shared by both kernels: lane holds, for pixel pl0 + 32*wave + (lane & 31) of image bt, outputs
-// n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i).  Output tiles never straddle images (the last tile of an image is ragged).  `scratch` = LDS beyond the (now idle) staging ring: 2 * 32 NT floats per wave for the statistics.
-template <typename T, int NS, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                              int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
+// n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i).  Output tiles never straddle images (the last tile of an image is ragged).  `scratch` = LDS beyond the (now
+// idle) staging ring: 2 * 32 NT floats per wave for the statistics.  One pass handles the n-tiles [NT0, NT0 + NTP) of the
+// wave's NT (the transposed tile of a pass must fit the ring: conv_epilogue below picks the pass width).
+template <typename T, int NS, int NT, int NT0, int NTP, int WSTRIDE>   // WSTRIDE: bytes of a wave's private staging block
+__device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
+                                                   int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
     const int P = a.Ho * a.Wo;                                    // pixels per image
     // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
     // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
-    constexpr int ROWB = 32 * NT * 4;                             // bytes per pixel row of the tile
-    unsigned char* stg = lds + wave * (32 * ROWB);
+    constexpr int ROWB = 32 * NTP * 4;                            // bytes per pixel row of the pass's tile
+    const int nb = n0 + 32 * NT0;                                 // first output channel of the pass
+    unsigned char* stg = lds + wave * WSTRIDE;                    // same block in every pass: waves are not synchronised
     const int tl = lane & 31;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTP; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = n0 + 32 * nt + 8 * g + 4 * half;
+            const int n = nb + 32 * nt + 8 * g + 4 * half;
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[i] = acc[nt][4 * g + i] * a.out_scale;
+                v[i] = acc[NT0 + nt][4 * g + i] * a.out_scale;
                 if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
                 if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
                 else if (a.act == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
@@ -93,8 +98,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
         // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  nv = valid pixels of this wave
         // (32 except in the ragged last tile of an image).
-        float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT);
-        for (int ch = lane; ch < 32 * NT; ch += 64) {
+        float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT) + 32 * NT0;
+        for (int ch = lane; ch < 32 * NTP; ch += 64) {
             const int c = ch >> 2, ci = ch & 3;
             const int nv = min(32, max(0, P - (pl0 + 32 * wave)));
             const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
@@ -114,8 +119,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         __syncthreads();
         // threads 0 .. 32 NT - 1 of every group of four waves merge that group's 128 pixels
         const int grp = tid >> 8, gt = tid & 255;
-        if (gt < 32 * NT && n0 + gt < a.Cout && pl0 + 128 * grp < P) {
-            const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT);
+        if (gt < 32 * NTP && nb + gt < a.Cout && pl0 + 128 * grp < P) {
+            const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT) + 32 * NT0;
             const int tid = gt;
             float mean = w0[tid], m2 = w0[32 * NT + tid];
             float n = (float)min(32, P - (pl0 + 128 * grp));                 // wave 0 of the group always has valid pixels
@@ -131,13 +136,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                 }
             }
             const int tiles128 = (P + 127) / 128;                           // statistics parts per image
-            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + n0 + tid;
+            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + nb + tid;
             pr[0] = mean;
             pr[a.Cout] = 0.f;
             pr[2 * a.Cout] = m2;
         }
     }
-    constexpr int CPR = 8 * NT;                                   // 16-byte chunks per row
+    constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
     constexpr int ITER = 32 * CPR / 64;
     const int rloc0 = pl0 + 32 * wave;                            // first pixel of this wave inside the image
 #pragma unroll
@@ -145,9 +150,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         const int idx = it * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-        if (rloc0 + r < P && n0 + 4 * c < a.Cout) {
+        if (rloc0 + r < P && nb + 4 * c < a.Cout) {
             const long row = (long)bt * P + rloc0 + r;
-            int col = n0 + 4 * c;
+            int col = nb + 4 * c;
             f32x4 d = d0;
             bool to_out = a.out != nullptr, to_planes = a.outp != nullptr;
             if (a.gate == 1) {
@@ -182,6 +187,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     }
 }
 
+// NTE = n-tiles per epilogue pass (NT: the whole tile at once).
+template <typename T, int NS, int NT, int NTE = NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
+                                              int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
+    constexpr int NP = NTE < NT ? NTE : NT;
+    constexpr int WSTRIDE = 32 * (32 * NP * 4);
+    conv_epilogue_pass<T, NS, NT, 0, NP, WSTRIDE>(a, acc, lds, scratch, bt, pl0, n0, tid, wave, lane, half);
+    if constexpr (NTE < NT)          // the wave's staging block is private and DS operations of a wave execute in order
+        conv_epilogue_pass<T, NS, NT, NTE, NT - NTE, WSTRIDE>(a, acc, lds, scratch, bt, pl0, n0, tid, wave, lane, half);
+}
+
 template <typename T, int NS, int NT>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     constexpr int TILE = 128 * 64;               // one 128-row x 64-byte operand tile (one plane, one stage)
@@ -195,8 +211,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int P = a.Ho * a.Wo, tpi = (P + 127) / 128;            // pixels / 128-pixel tiles per image
-    const int bt = blockIdx.x / tpi, pl0 = (blockIdx.x - bt * tpi) * 128;
-    const int n0 = blockIdx.y * (32 * NT);
+    // 1-D grid, XCD-aware: every XCD (own L2) gets a contiguous range of (pixel tile, channel tile) pairs, channel tile
+    // fastest -- the workgroups that share an activation tile and the neighbours that share its halo rows hit the same L2
+    const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);
+    const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = wg / ny;
+    const int bt = tile / tpi, pl0 = (tile - bt * tpi) * 128;
+    const int n0 = (wg - tile * ny) * (32 * NT);
     const int cpt = a.Cin >> 5;                  // 32-channel chunks per tap
     const int nstage = a.KH * a.KW * cpt;
     const int ktot = a.KH * a.KW * a.Cin;
@@ -327,6 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 // (fragment reads at row offset kx) next to the KW weight tiles: 2.5x fewer LDS-DMA instructions and 3x fewer barriers per
 // MFMA than the generic kernel at NT = 2 (its measured limiter).  Taps that cross the left / right image border are zeroed
 // per lane at fragment level; rows above / below the image (and outside the batch) are staged from the zero row.
+#ifndef UM_CONV_ABL
+#define UM_CONV_ABL 0                           // diagnostics builds only (tools/ab_bench.py, UM_LIB)
+#endif
 template <typename T, int NS, int NT, int KW>
 __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
     constexpr int WROWS = 272;                   // 17 DMA blocks of 16 rows >= 256 + KW - 1
@@ -341,8 +365,11 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, fr = lane & 31;
     const int P = a.Ho * a.Wo, tpi = (P + 255) / 256;            // pixels / 256-pixel tiles per image
-    const int bt = blockIdx.x / tpi, pl0 = (blockIdx.x - bt * tpi) * 256;
-    const int n0 = blockIdx.y * (32 * NT);
+    const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);           // 1-D XCD-aware grid, see conv_kernel
+    const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = wg / ny;
+    const int bt = tile / tpi, pl0 = (tile - bt * tpi) * 256;
+    const int n0 = (wg - tile * ny) * (32 * NT);
     const int cpt = a.Cin >> 5;
     const int nstage = a.KH * cpt;
     const int ktot = a.KH * KW * a.Cin;
@@ -368,7 +395,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
         for (int i = 0; i < 3; ++i) {
             const int iy = wy[i] + ky;
             const bool ok = wok[i] && (unsigned)iy < (unsigned)a.Hi;
-            const unsigned row = ok ? (unsigned)(wflat[i] + (long)ky * a.Wi) : a.zero_row;
+            unsigned row = ok ? (unsigned)(wflat[i] + (long)ky * a.Wi) : a.zero_row;
+#if UM_CONV_ABL == 1                             // diagnostics: every window row from the same 16 rows (always cache hits)
+            row &= 15u;
+#endif
             rowoff[i] = row * a.row_stride;
         }
     };
@@ -460,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
             const unsigned char* wt = cur + NS * ATILE + kx * NS * WTILE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (more) {                                       // this group's share of the next stage's pieces
+                if (more && UM_CONV_ABL != 3) {                   // this group's share of the next stage's pieces
                     constexpr int GROUPS = 2 * KW - 2;            // the last two groups issue nothing: their DMA would be
                     const int g = 2 * kx + ks;                    // waited for at once
 #pragma unroll
@@ -483,6 +513,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
                         acc[nt] = T::mfma(wl, bh, acc[nt]);
                         acc[nt] = T::mfma(wh, bl, acc[nt]);
                     }
+#if UM_CONV_ABL == 2                             // diagnostics: one product instead of three
+                    if (NS == 1)
+#endif
                     acc[nt] = T::mfma(wh, bh, acc[nt]);
                 }
             }
@@ -495,6 +528,183 @@ __global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
     conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
 }
 
+// ---- row-window variant with 16-channel stages ---------------------------------------------------------------------------------
+// Same window idea, but a stage is (ky, 16 channels): rows of 32 bytes, half the ring.  At NT = 2 / 3 that lets TWO
+// workgroups share a CU (<= 80 KB each, <= 128 VGPRs): the encoder's convolutions have only K = 576 .. 1152 (a handful of
+// stages), so with one workgroup per CU its prologue (first DMA latency) and epilogue (transpose, 64 .. 96 KB of stores, all
+// CUs in phase) ran with the matrix pipes idle -- measured: dropping 2/3 of the MFMAs or all of the main-loop DMA changed the
+// kernel time by < 15 %.  At NT = 4 (refinement block: 1x5 GRU gates, 3x3 -> 128 / 256) it is what fits the window + KW
+// weight tiles into LDS at all.  Layout: 16-byte chunk c (0 / 1) of row r sits at chunk c ^ ((r >> 3) & 1), which makes the
+// ds_read_b128 lane groups of a 32-row fragment conflict-free; one DMA instruction moves 32 rows.
+template <int NS, int NT, int KW>
+struct ConvRows16Lds {
+    static constexpr int NTE = NT < 2 ? NT : 2;                   // epilogue pass width
+    static constexpr int ATILE = 288 * 32;                        // 9 DMA blocks of 32 rows >= 256 + KW - 1
+    static constexpr int WTILE = 32 * NT * 32;
+    static constexpr int STAGE = NS * (ATILE + KW * WTILE);
+    static constexpr int EPI = 8 * 32 * (32 * NTE * 4);
+    static constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4;
+};
+
+template <typename T, int NS, int NT, int KW>
+__global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_rows16_kernel(ConvArgs a) {
+    using L = ConvRows16Lds<NS, NT, KW>;
+    constexpr int ATILE = L::ATILE, WTILE = L::WTILE, STAGE = L::STAGE, RING = L::RING;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, fr = lane & 31;
+    const int P = a.Ho * a.Wo, tpi = (P + 255) / 256;
+    const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);           // 1-D XCD-aware grid, see conv_kernel
+    const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = wg / ny;
+    const int bt = tile / tpi, pl0 = (tile - bt * tpi) * 256;
+    const int n0 = (wg - tile * ny) * (32 * NT);
+    const int cpt = a.Cin >> 4;                  // 16-channel chunks per tap
+    const int nstage = a.KH * cpt;
+    const int ktot = a.KH * KW * a.Cin;
+
+    // ---- window rows this lane stages: block jr (32 rows), row j = 32 jr + (lane >> 1); blocks 0..7 by wave jr, block 8 by
+    // wave 7 (which has no weight block at KW NT <= 7)
+    const int dcp = lane & 1;
+    int wy[2];
+    long wflat[2];
+    bool wok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int jr = i == 0 ? wave : 8;
+        const int j = 32 * jr + (lane >> 1);
+        const int p = pl0 + j - a.pad_w;
+        wok[i] = (i == 0 || wave == 7) && p >= 0 && p < P;
+        const int rem = wok[i] ? p : 0;
+        wy[i] = rem / a.Wo - a.pad_h;
+        wflat[i] = (long)bt * P + rem - (long)a.pad_h * a.Wi;
+    }
+    unsigned rowoff[2];
+    auto set_ky = [&](int ky) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = wy[i] + ky;
+            const bool ok = wok[i] && (unsigned)iy < (unsigned)a.Hi;
+            const unsigned row = ok ? (unsigned)(wflat[i] + (long)ky * a.Wi) : a.zero_row;
+            rowoff[i] = row * a.row_stride;
+        }
+    };
+    // staging pieces of a wave: 0 / 1 = window blocks, 2.. = weight blocks (tap kx, 32 output rows jb)
+    constexpr int NPIECE = 2 + (KW * NT + 7) / 8;
+    auto stage_piece = [&](int k, int ky, int cc, unsigned char* buf) {
+        if (k < 2) {
+            const int jr = k == 0 ? wave : 8;
+            if (k == 0 || wave == 7) {
+                const int r = 32 * jr + (lane >> 1);
+                const int sc = dcp ^ ((r >> 3) & 1);
+                const unsigned off = rowoff[k] + (unsigned)((cc * 16 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * ATILE + (32 * jr) * 32);
+            }
+        } else {
+            const int q = wave + 8 * (k - 2);
+            if (q < KW * NT) {
+                const int kx = q / NT, jb = q - kx * NT;
+                const int r = 32 * jb + (lane >> 1);
+                const int sc = dcp ^ ((r >> 3) & 1);
+                const int n = min(n0 + r, a.Cout - 1);
+                const unsigned off = (unsigned)(((long)n * ktot + (ky * KW + kx) * a.Cin + cc * 16 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * ATILE + (kx * NS + pl) * WTILE + (32 * jb) * 32);
+            }
+        }
+    };
+
+    bool tap_ok[KW];
+    bool any_masked = false;
+    {
+        const int p = pl0 + 32 * wave + fr;
+        const bool pok = p < P;
+        const int x = (pok ? p : 0) % a.Wo;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            tap_ok[kx] = pok && (unsigned)(x + kx - a.pad_w) < (unsigned)a.Wi;
+            any_masked |= !tap_ok[kx];
+        }
+    }
+    const bool wave_masked = __any(any_masked);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // fragment offsets (one k-step of 16 channels per stage): weights row fr; activations window row 32 wave + fr + kx
+    const int foffw = fr * 32 + ((half ^ ((fr >> 3) & 1)) << 4);
+    int foffa[KW];
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+        const int r = 32 * wave + fr + kx;
+        foffa[kx] = r * 32 + ((half ^ ((r >> 3) & 1)) << 4);
+    }
+
+    int ky = 0, cc = 0;                          // position of the NEXT stage to be issued
+    set_ky(0);
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) stage_piece(k, 0, 0, lds);
+    auto advance = [&]() {
+        if (++cc == cpt) {
+            cc = 0;
+            ++ky;
+            set_ky(ky);
+        }
+    };
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = 0; s < nstage; ++s) {
+        unsigned char* cur = lds + (s & 1) * STAGE;
+        unsigned char* nxt = lds + ((s & 1) ^ 1) * STAGE;
+        const bool more = s + 1 < nstage;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const unsigned char* wt = cur + NS * ATILE + kx * NS * WTILE;
+            if (more) {                                           // the next stage's pieces, spread over the first KW - 1 taps
+                constexpr int GROUPS = KW - 1;
+#pragma unroll
+                for (int k = 0; k < NPIECE; ++k)
+                    if (k % GROUPS == kx && kx < GROUPS) stage_piece(k, ky, cc, nxt);
+            }
+            i16x8 bh = *reinterpret_cast<const i16x8*>(cur + foffa[kx]);
+            i16x8 bl;
+            if (NS == 2) bl = *reinterpret_cast<const i16x8*>(cur + ATILE + foffa[kx]);
+            if (wave_masked && !tap_ok[kx]) {
+                const i16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                bh = z;
+                bl = z;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 32 + foffw);
+                if (NS == 2) {
+                    const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 32 + foffw);
+                    acc[nt] = T::mfma(wl, bh, acc[nt]);
+                    acc[nt] = T::mfma(wh, bl, acc[nt]);
+                }
+                acc[nt] = T::mfma(wh, bh, acc[nt]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
+}
+
+
 template <int NS, int NT, int KW>
 struct ConvRowsLds {
     static constexpr int STAGE = NS * (272 * 64 + KW * 32 * NT * 64);
@@ -506,9 +716,14 @@ struct ConvRowsLds {
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
 
+static int conv_xcd_enabled() {
+    static const int on = getenv("UM_CONV_NO_XCD") == nullptr;     // A/B switch (tools/ab_bench.py), read once
+    return on;
+}
+
 template <int NT>
 static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
-    dim3 grid(a.B * ((a.Ho * a.Wo + 127) / 128), (a.Cout + 32 * NT - 1) / (32 * NT)), block(256);
+    dim3 grid(a.B * ((a.Ho * a.Wo + 127) / 128) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(256);
     ScopedKernelTimer timer(UM_K_CONV, stream);
     if (mode == 0)
         hipLaunchKernelGGL((conv_kernel<Fp16, 2, NT>), grid, block, 0, stream, a);
@@ -520,7 +735,7 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
 template <int NT, int KW>
 static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stream) {
     static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
-    dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256), (a.Cout + 32 * NT - 1) / (32 * NT)), block(512);
+    dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
     constexpr int LDS2 = ConvRowsLds<2, NT, KW>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW>::TOTAL;
     ScopedKernelTimer timer(UM_K_CONV, stream);
     if (mode == 0) {
@@ -539,6 +754,32 @@ static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stre
             configured[1] = true;
         }
         hipLaunchKernelGGL((conv_rows_kernel<Bf16, 1, NT, KW>), grid, block, LDS1, stream, a);
+    }
+    return hipGetLastError();
+}
+
+template <int NT, int KW>
+static hipError_t launch_conv_rows16(const ConvArgs& a, int mode, hipStream_t stream) {
+    static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
+    dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
+    constexpr int LDS2 = ConvRows16Lds<2, NT, KW>::TOTAL, LDS1 = ConvRows16Lds<1, NT, KW>::TOTAL;
+    ScopedKernelTimer timer(UM_K_CONV, stream);
+    if (mode == 0) {
+        if (!configured[0]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<Fp16, 2, NT, KW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            if (e != hipSuccess) return e;
+            configured[0] = true;
+        }
+        hipLaunchKernelGGL((conv_rows16_kernel<Fp16, 2, NT, KW>), grid, block, LDS2, stream, a);
+    } else {
+        if (!configured[1]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<Bf16, 1, NT, KW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            if (e != hipSuccess) return e;
+            configured[1] = true;
+        }
+        hipLaunchKernelGGL((conv_rows16_kernel<Bf16, 1, NT, KW>), grid, block, LDS1, stream, a);
     }
     return hipGetLastError();
 }
@@ -612,13 +853,23 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     a.gate_z = gate_z;
     a.gate_zld = gate_zld;
     a.out_scale = ldexpf(1.f, -wshift);
+    a.xcd = conv_xcd_enabled();
     hipError_t e;
     // widest output tile that does not waste more than a third of its columns
     const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
     // same-size stride-1 3-tap rows: the row-window kernel (its LDS budget allows 64- and 96-wide output tiles)
     static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
     const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && (long)ho * wo >= 256 && rows_enabled;
-    if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
+    // 16-channel-stage row window: UM_CONV_ROWS16 = the tile widths (digits of NT) it may serve, A/B switch read once
+    static const char* rows16_env = getenv("UM_CONV_ROWS16");
+    static const char* rows16_nts = rows16_env ? rows16_env : "234";
+    const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;
+    const bool rows16 = same && ((kw == 3 && pad_w == 1) || (kw == 5 && pad_w == 2 && nt == 4)) && strchr(rows16_nts, '0' + nt) != nullptr;
+    if (rows16 && nt == 2) e = launch_conv_rows16<2, 3>(a, mode, (hipStream_t)stream_);
+    else if (rows16 && nt == 3) e = launch_conv_rows16<3, 3>(a, mode, (hipStream_t)stream_);
+    else if (rows16 && nt == 4 && kw == 3) e = launch_conv_rows16<4, 3>(a, mode, (hipStream_t)stream_);
+    else if (rows16 && nt == 4) e = launch_conv_rows16<4, 5>(a, mode, (hipStream_t)stream_);
+    else if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
     else if (rows && nt == 3) e = launch_conv_rows<3, 3>(a, mode, (hipStream_t)stream_);
     else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
     else if (nt == 3) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
@@ -791,6 +1042,7 @@ extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, con
     a.gate_h = nullptr;
     a.gate_z = nullptr;
     a.out_scale = ldexpf(1.f, -wshift);
+    a.xcd = conv_xcd_enabled();
     hipError_t e;
     if (cout % 128 == 0 || cout > 192) e = launch_conv<4>(a, 0, stream);
     else if (cout % 96 == 0) e = launch_conv<3>(a, 0, stream);
