@@ -149,7 +149,8 @@ int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void
  *   a_planes : activations as operand planes [NS][batch*hi*wi + 1][cin], NHWC, whose LAST row is all zeros (taps outside
  *              the image read it).  Written by um_nhwc_instance_norm / um_nchw_to_nhwc.  cin: multiple of 32.
  *   w_planes : um_weight_planes() of the weight permuted to [cout][kh][kw][cin] (n = cout, k = kh*kw*cin), same wshift.
- *   out      : fp32 [batch*ho*wo][cout] (NHWC), ho = (hi + 2 pad_h - kh) / stride + 1; + bias[cout] if not NULL; ReLU if relu.
+ *   out      : fp32 [batch*ho*wo][cout] (NHWC), ho = (hi + 2 pad_h - kh) / stride + 1; + bias[cout] if not NULL (16-byte
+ *              aligned); ReLU if relu.
  * ------------------------------------------------------------------------------------------- */
 int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out, int batch,
                   int hi, int wi, int cin, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int relu, int wshift,

@@ -121,6 +121,21 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / iters * 1e3
             print(f'     MIOpen fp32 same conv                       {ms:8.4f} ms     {fl / ms / 1e9:8.1f} TF/s', flush=True)
+    if 'conv' in what:
+        # refinement-block convolutions at config 4 (4 pairs @ 1/4 resolution = 128 x 192)
+        nb, hh, ww = 4, 128, 192
+        rows = nb * hh * ww
+        for (cin, cout, ks, pad, tag) in ((384, 256, (1, 5), (0, 2), 'GRU z|r 1x5 384->256'), (384, 128, (1, 5), (0, 2), 'GRU q 1x5 384->128'),
+                                          (384, 256, (5, 1), (2, 0), 'GRU z|r 5x1 384->256'), (256, 192, (3, 3), (1, 1), 'convc2 3x3 256->192'),
+                                          (256, 128, (3, 3), (1, 1), 'motion 3x3 256->128'), (128, 256, (3, 3), (1, 1), 'flow head 3x3 128->256')):
+            src = ops.planes_buffer(rows, cin)
+            ops.nhwc_gate(0, torch.randn(rows, cin, device=dev, generator=g), src, cin, 0, rows, cin)
+            wt = torch.randn(cout, cin, ks[0], ks[1], device=dev, generator=g) * 0.03
+            wb = (ops.conv_weight_planes_from(wt), None)
+            out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+            fl = 2.0 * rows * cout * ks[0] * ks[1] * cin
+            run(f'conv {tag} @128x192 x4', lambda: ops.conv_ex((src, cin, 0, cin), (nb, hh, ww), wb, ks, 1, pad, 1, out=(out, cout, 0)),
+                fl, lib, iters, 'conv', issued)
     if 'gsv' in what:
         B, h, w = 8, 64, 96
         L = h * w

@@ -17,7 +17,6 @@
 // Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
 // computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
 #include <cstdlib>
-#include <cstring>
 #include "common.h"
 #include "planes.h"
 
@@ -65,70 +64,114 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
 // n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i).  Output tiles never straddle images (the last tile of an image is ragged).  `scratch` = LDS beyond the (now
 // idle) staging ring: 2 * 32 NT floats per wave for the statistics.  One pass handles the n-tiles [NT0, NT0 + NTP) of the
 // wave's NT (the transposed tile of a pass must fit the ring: conv_epilogue below picks the pass width).
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+
 template <typename T, int NS, int NT, int NT0, int NTP, int WSTRIDE>   // WSTRIDE: bytes of a wave's private staging block
 __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
                                                    int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
     const int P = a.Ho * a.Wo;                                    // pixels per image
-    // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NT block; 16-byte chunk c of
+    // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NTP block; 16-byte chunk c of
     // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
+    // The wave-uniform switches (activation, gate mode) are taken ONCE around straight-line loops: with K = 576 .. 1152 the
+    // encoder's convolutions spend as many issue cycles here as in their main loop.
     constexpr int ROWB = 32 * NTP * 4;                            // bytes per pixel row of the pass's tile
     const int nb = n0 + 32 * NT0;                                 // first output channel of the pass
     unsigned char* stg = lds + wave * WSTRIDE;                    // same block in every pass: waves are not synchronised
     const int tl = lane & 31;
+    auto to_lds = [&](auto act_tag, auto bias_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool BIAS = decltype(bias_tag)::value != 0;
 #pragma unroll
-    for (int nt = 0; nt < NTP; ++nt)
+        for (int nt = 0; nt < NTP; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = nb + 32 * nt + 8 * g + 4 * half;
-            f32x4 v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 32 * nt + 8 * g + 4 * half;
+                f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = acc[NT0 + nt][4 * g + i] * a.out_scale;
-                if (a.bias) v[i] += a.bias[min(n + i, a.Cout - 1)];
-                if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
-                else if (a.act == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
-                else if (a.act == 3) v[i] = tanhf(v[i]);
+                for (int i = 0; i < 4; ++i) v[i] = acc[NT0 + nt][4 * g + i] * a.out_scale;
+                if (BIAS) v = v + *reinterpret_cast<const f32x4*>(a.bias + min(n, a.Cout - 4));   // columns >= Cout are dropped below
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (ACT == 1) v[i] = fmaxf(v[i], 0.f);
+                    else if (ACT == 2) v[i] = 1.0f / (1.0f + __expf(-v[i]));
+                    else if (ACT == 3) v[i] = tanhf(v[i]);
+                }
+                const int c = 8 * nt + 2 * g + half;             // 16-byte chunk index inside the row
+                *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
             }
-            const int c = 8 * nt + 2 * g + half;                 // 16-byte chunk index inside the row
-            *reinterpret_cast<f32x4*>(stg + tl * ROWB + ((c ^ (tl & 7)) << 4)) = v;
-        }
+    };
+    auto to_lds_b = [&](auto act_tag) {
+        if (a.bias) to_lds(act_tag, IntC<1>{});
+        else to_lds(act_tag, IntC<0>{});
+    };
+    switch (a.act) {
+        case 0: to_lds_b(IntC<0>{}); break;
+        case 1: to_lds_b(IntC<1>{}); break;
+        case 2: to_lds_b(IntC<2>{}); break;
+        default: to_lds_b(IntC<3>{}); break;
+    }
     __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
+    const int rloc0 = pl0 + 32 * wave;                            // first pixel of this wave inside the image
     if (a.stats) {
         // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
-        // Per wave: 32 pixels, shifted by the first one (no cancellation); the four waves are merged with the
-        // parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).  nv = valid pixels of this wave
-        // (32 except in the ragged last tile of an image).
-        float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT) + 32 * NT0;
-        for (int ch = lane; ch < 32 * NTP; ch += 64) {
-            const int c = ch >> 2, ci = ch & 3;
-            const int nv = min(32, max(0, P - (pl0 + 32 * wave)));
-            const float k = *reinterpret_cast<const float*>(stg + ((c ^ 0) << 4) + ci * 4);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const float d = *reinterpret_cast<const float*>(stg + r * ROWB + ((c ^ (r & 7)) << 4) + ci * 4) - k;
-                if (r < nv) {
-                    s1 += d;
-                    s2 = __builtin_fmaf(d, d, s2);
+        // Per wave: its valid pixels (32 except in the ragged last tile of an image), shifted by the first one (no
+        // cancellation); lane = (chunk of 4 channels, group of rows); the row groups are folded with shuffles; the four waves of
+        // 128 pixels are merged with the parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).
+        constexpr int RG = 64 / CPR >= 8 ? 8 : 64 / CPR >= 4 ? 4 : 2;       // row groups (lanes beyond RG * CPR idle)
+        constexpr int RPG = 32 / RG;
+        const int nv = min(32, max(0, P - rloc0));
+        const int c = lane % CPR, rg = lane / CPR;
+        const f32x4 k = *reinterpret_cast<const f32x4*>(stg + (c << 4));                     // row 0 (chunk c ^ 0)
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (rg < RG) {
+            if (nv == 32) {
+#pragma unroll
+                for (int j = 0; j < RPG; ++j) {
+                    const int r = rg * RPG + j;
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4)) - k;
+                    s1 = s1 + d;
+                    s2 = s2 + d * d;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RPG; ++j) {
+                    const int r = rg * RPG + j;
+                    f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4)) - k;
+                    if (r >= nv) d = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s1 = s1 + d;
+                    s2 = s2 + d * d;
                 }
             }
+        }
+#pragma unroll
+        for (int step = CPR * RG / 2; step >= CPR; step >>= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s1[i] += __shfl_down(s1[i], step, 64);
+                s2[i] += __shfl_down(s2[i], step, 64);
+            }
+        float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT) + 32 * NT0;
+        if (lane < CPR) {
             const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
-            ws[ch] = k + s1 * inv;                                          // mean of the wave's valid pixels
-            ws[32 * NT + ch] = s2 - s1 * s1 * inv;                          // sum of squared deviations
+            *reinterpret_cast<f32x4*>(ws + 4 * c) = k + s1 * inv;                            // mean of the wave's valid pixels
+            *reinterpret_cast<f32x4*>(ws + 32 * NT + 4 * c) = s2 - s1 * s1 * inv;            // sum of squared deviations
         }
         __syncthreads();
-        // threads 0 .. 32 NT - 1 of every group of four waves merge that group's 128 pixels
+        // threads 0 .. 32 NTP - 1 of every group of four waves merge that group's 128 pixels
         const int grp = tid >> 8, gt = tid & 255;
         if (gt < 32 * NTP && nb + gt < a.Cout && pl0 + 128 * grp < P) {
             const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT) + 32 * NT0;
-            const int tid = gt;
-            float mean = w0[tid], m2 = w0[32 * NT + tid];
+            float mean = w0[gt], m2 = w0[32 * NT + gt];
             float n = (float)min(32, P - (pl0 + 128 * grp));                 // wave 0 of the group always has valid pixels
 #pragma unroll
             for (int wv = 1; wv < 4; ++wv) {
                 const float nw = (float)min(32, max(0, P - (pl0 + 128 * grp + 32 * wv)));
                 if (nw > 0.f) {
-                    const float mw = w0[wv * (2 * 32 * NT) + tid], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + tid];
+                    const float mw = w0[wv * (2 * 32 * NT) + gt], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + gt];
                     const float delta = mw - mean, nn = n + nw;
                     mean += delta * (nw / nn);
                     m2 += m2w + delta * delta * (n * nw / nn);
@@ -136,55 +179,63 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                 }
             }
             const int tiles128 = (P + 127) / 128;                           // statistics parts per image
-            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + nb + tid;
+            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + nb + gt;
             pr[0] = mean;
             pr[a.Cout] = 0.f;
             pr[2 * a.Cout] = m2;
         }
     }
-    constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
+    // ---- full-row stores: wave-uniform 64-bit bases, 32-bit lane offsets
     constexpr int ITER = 32 * CPR / 64;
-    const int rloc0 = pl0 + 32 * wave;                            // first pixel of this wave inside the image
+    const long rowbase = (long)bt * P + rloc0;                    // first output row of this wave
+    const int nrows = min(32, P - rloc0);                         // valid rows (<= 0: none)
+    auto store_rows = [&](auto gate_tag) {
+        constexpr int GATE = decltype(gate_tag)::value;
+        float* obase = a.out ? a.out + rowbase * a.out_ld + a.out_coff : nullptr;
+        unsigned short* pbase = a.outp ? a.outp + rowbase * a.outp_ld + a.outp_coff : nullptr;
+        float* hbase = GATE ? a.gate_h + rowbase * a.gate_c : nullptr;
+        const float* zbase = GATE == 2 ? a.gate_z + rowbase * a.gate_zld : nullptr;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int idx = it * 64 + lane;
-        const int r = idx / CPR, c = idx - r * CPR;
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-        if (rloc0 + r < P && nb + 4 * c < a.Cout) {
-            const long row = (long)bt * P + rloc0 + r;
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = it * 64 + lane;
+            const int r = idx / CPR, c = idx - r * CPR;
+            f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
             int col = nb + 4 * c;
-            f32x4 d = d0;
-            bool to_out = a.out != nullptr, to_planes = a.outp != nullptr;
-            if (a.gate == 1) {
-                if (col >= a.gate_c) {
-                    col -= a.gate_c;
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(a.gate_h + row * a.gate_c + col);
-                    d = d * hv;
-                    to_out = false;
-                } else {
-                    to_planes = false;
-                }
-            } else if (a.gate == 2) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(a.gate_z + row * a.gate_zld + col);
-                float* hp = a.gate_h + row * a.gate_c + col;
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);
+            if (r < nrows && col < a.Cout) {
+                bool to_out = obase != nullptr, to_planes = pbase != nullptr;
+                if (GATE == 1) {
+                    if (col >= a.gate_c) {
+                        col -= a.gate_c;
+                        d = d * *reinterpret_cast<const f32x4*>(hbase + (unsigned)(r * a.gate_c + col));
+                        to_out = false;
+                    } else {
+                        to_planes = false;
+                    }
+                } else if (GATE == 2) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(zbase + (unsigned)(r * a.gate_zld + col));
+                    float* hp = hbase + (unsigned)(r * a.gate_c + col);
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i] = (1.0f - z[i]) * hv[i] + z[i] * d[i];
-                *reinterpret_cast<f32x4*>(hp) = d;
-            }
-            if (to_out) *reinterpret_cast<f32x4*>(a.out + row * a.out_ld + a.out_coff + col) = d;
-            if (to_planes) {
-                unsigned short* dst = a.outp + row * a.outp_ld + a.outp_coff + col;
-                const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
-                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-                if (NS == 2) {
-                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                    *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
-                        u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                    for (int i = 0; i < 4; ++i) d[i] = (1.0f - z[i]) * hv[i] + z[i] * d[i];
+                    *reinterpret_cast<f32x4*>(hp) = d;
+                }
+                if (to_out) *reinterpret_cast<f32x4*>(obase + (unsigned)(r * a.out_ld + col)) = d;
+                if (to_planes) {
+                    unsigned short* dst = pbase + (unsigned)(r * a.outp_ld + col);
+                    const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                    if (NS == 2) {
+                        const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
+                        *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
+                            u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                    }
                 }
             }
         }
-    }
+    };
+    if (a.gate == 0) store_rows(IntC<0>{});
+    else if (a.gate == 1) store_rows(IntC<1>{});
+    else store_rows(IntC<2>{});
 }
 
 // NTE = n-tiles per epilogue pass (NT: the whole tile at once).
@@ -250,9 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     int ky = 0, kx = 0, cc = 0;                  // position of the NEXT stage to be issued
     // 16-byte chunk cp of row r holds source chunk cp ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
     auto stage_async = [&](int c0, int kglob, unsigned char* buf) {
-#ifdef UM_CONV_ABL_A
-        if (kx == 1 || a.KW != 3)
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * wave + 16 * i + (lane >> 2);
@@ -340,216 +388,57 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
 }
 
-// ---- row-window variant: same-size stride-1 convolutions with KW > 1 horizontal taps ------------------------------------------
+// ---- row-window variant: same-size stride-1 convolutions with KW = 3 / 5 horizontal taps -------------------------------------
 // In the generic kernel every tap stages its own [128 x 32] activation tile, although the KW horizontal taps of one kernel row
 // read the SAME input pixels shifted by one: with flat pixel indices (output and input images have the same shape) tap
 // (ky, kx) of output pixel p is input pixel p + (ky - ph) W + (kx - pw).  Here a workgroup of 8 waves owns 256 consecutive
-// output pixels and, per (ky, 32-channel chunk), stages ONE window of 256 + KW - 1 input rows that serves all KW taps
-// (fragment reads at row offset kx) next to the KW weight tiles: 2.5x fewer LDS-DMA instructions and 3x fewer barriers per
-// MFMA than the generic kernel at NT = 2 (its measured limiter).  Taps that cross the left / right image border are zeroed
-// per lane at fragment level; rows above / below the image (and outside the batch) are staged from the zero row.
-#ifndef UM_CONV_ABL
-#define UM_CONV_ABL 0                           // diagnostics builds only (tools/ab_bench.py, UM_LIB)
-#endif
-template <typename T, int NS, int NT, int KW>
-__global__ __launch_bounds__(512, 2) void conv_rows_kernel(ConvArgs a) {
-    constexpr int WROWS = 272;                   // 17 DMA blocks of 16 rows >= 256 + KW - 1
-    constexpr int ATILE = WROWS * 64;            // one plane of the window
-    constexpr int WTILE = 32 * NT * 64;          // one plane of one tap's weight tile
-    constexpr int STAGE = NS * (ATILE + KW * WTILE);
-    constexpr int EPI = 8 * 32 * (32 * NT * 4);
-    constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, fr = lane & 31;
-    const int P = a.Ho * a.Wo, tpi = (P + 255) / 256;            // pixels / 256-pixel tiles per image
-    const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);           // 1-D XCD-aware grid, see conv_kernel
-    const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int tile = wg / ny;
-    const int bt = tile / tpi, pl0 = (tile - bt * tpi) * 256;
-    const int n0 = (wg - tile * ny) * (32 * NT);
-    const int cpt = a.Cin >> 5;
-    const int nstage = a.KH * cpt;
-    const int ktot = a.KH * KW * a.Cin;
-
-    // ---- window rows this lane stages: DMA block jr = wave + 8 i (16 rows each), row j = 16 jr + (lane >> 2) ----------------
-    // validity is decided by the row's "central" user, output pixel pl0 + j - pw of image bt (see above)
-    const int dcp = lane & 3;
-    int wy[3];
-    long wflat[3];
-    bool wok[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = 16 * (wave + 8 * i) + (lane >> 2);
-        const int p = pl0 + j - a.pad_w;
-        wok[i] = (wave + 8 * i) < 17 && p >= 0 && p < P;
-        const int rem = wok[i] ? p : 0;
-        wy[i] = rem / a.Wo - a.pad_h;
-        wflat[i] = (long)bt * P + rem - (long)a.pad_h * a.Wi;       // same-size convolution: input pixels = output pixels
-    }
-    unsigned rowoff[3];
-    auto set_ky = [&](int ky) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int iy = wy[i] + ky;
-            const bool ok = wok[i] && (unsigned)iy < (unsigned)a.Hi;
-            unsigned row = ok ? (unsigned)(wflat[i] + (long)ky * a.Wi) : a.zero_row;
-#if UM_CONV_ABL == 1                             // diagnostics: every window row from the same 16 rows (always cache hits)
-            row &= 15u;
-#endif
-            rowoff[i] = row * a.row_stride;
-        }
-    };
-    // One staging "piece" = this wave's share of one DMA block (NS instructions).  Pieces 0..2: window blocks; 3..: weight
-    // blocks.  They are issued one by one between the MFMA groups of the previous stage (all eight waves of the workgroup
-    // run in lockstep, so a DMA burst at the top of the stage would leave the matrix pipe idle).
-    constexpr int NPIECE = 3 + (KW * 2 * NT + 7) / 8;
-    auto stage_piece = [&](int k, int ky, int cc, unsigned char* buf) {
-        if (k < 3) {
-            const int jr = wave + 8 * k;
-            if (jr < 17) {
-                const int r = 16 * jr + (lane >> 2);
-                const int sc = dcp ^ ((r >> 2) & 3);
-                const unsigned off = rowoff[k] + (unsigned)((cc * 32 + 8 * sc) * 2);
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * ATILE + (16 * jr) * 64);
-            }
-        } else {
-            const int q = wave + 8 * (k - 3);
-            if (q < KW * 2 * NT) {
-                const int kx = q / (2 * NT), jb = q - kx * (2 * NT);
-                const int r = 16 * jb + (lane >> 2);
-                const int sc = dcp ^ ((r >> 2) & 3);
-                const int n = min(n0 + r, a.Cout - 1);
-                const unsigned off = (unsigned)(((long)n * ktot + (ky * KW + kx) * a.Cin + cc * 32 + 8 * sc) * 2);
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl)
-                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + NS * ATILE + (kx * NS + pl) * WTILE + (16 * jb) * 64);
-            }
-        }
-    };
-
-    // ---- this lane's output pixel: which horizontal taps stay inside its image row ---------------------------------------
-    bool tap_ok[KW];
-    bool any_masked = false;
-    {
-        const int p = pl0 + 32 * wave + fr;
-        const bool pok = p < P;
-        const int x = (pok ? p : 0) % a.Wo;
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            tap_ok[kx] = pok && (unsigned)(x + kx - a.pad_w) < (unsigned)a.Wi;
-            any_masked |= !tap_ok[kx];
-        }
-    }
-    const bool wave_masked = __any(any_masked);                   // wave uniform
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-
-    // fragment offsets: weights row fr; activations window row 32 wave + fr + kx
-    int foffw[2], foffa[KW][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        foffw[ks] = fr * 64 + (((2 * ks + half) ^ ((fr >> 2) & 3)) << 4);
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            const int r = 32 * wave + fr + kx;
-            foffa[kx][ks] = r * 64 + (((2 * ks + half) ^ ((r >> 2) & 3)) << 4);
-        }
-    }
-
-    // ---- prologue: stage 0 ------------------------------------------------------------------------------------------------
-    int ky = 0, cc = 0;                          // position of the NEXT stage to be issued
-    set_ky(0);
-#pragma unroll
-    for (int k = 0; k < NPIECE; ++k) stage_piece(k, 0, 0, lds);
-    auto advance = [&]() {
-        if (++cc == cpt) {
-            cc = 0;
-            ++ky;
-            set_ky(ky);
-        }
-    };
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int s = 0; s < nstage; ++s) {
-        unsigned char* cur = lds + (s & 1) * STAGE;
-        unsigned char* nxt = lds + ((s & 1) ^ 1) * STAGE;
-        const bool more = s + 1 < nstage;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            const unsigned char* wt = cur + NS * ATILE + kx * NS * WTILE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (more && UM_CONV_ABL != 3) {                   // this group's share of the next stage's pieces
-                    constexpr int GROUPS = 2 * KW - 2;            // the last two groups issue nothing: their DMA would be
-                    const int g = 2 * kx + ks;                    // waited for at once
-#pragma unroll
-                    for (int k = 0; k < NPIECE; ++k)
-                        if (k % GROUPS == g && g < GROUPS) stage_piece(k, ky, cc, nxt);
-                }
-                i16x8 bh = *reinterpret_cast<const i16x8*>(cur + foffa[kx][ks]);
-                i16x8 bl;
-                if (NS == 2) bl = *reinterpret_cast<const i16x8*>(cur + ATILE + foffa[kx][ks]);
-                if (wave_masked && !tap_ok[kx]) {                  // this lane's tap is in the neighbouring image row
-                    const i16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    bh = z;
-                    bl = z;
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 64 + foffw[ks]);
-                    if (NS == 2) {
-                        const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 64 + foffw[ks]);
-                        acc[nt] = T::mfma(wl, bh, acc[nt]);
-                        acc[nt] = T::mfma(wh, bl, acc[nt]);
-                    }
-#if UM_CONV_ABL == 2                             // diagnostics: one product instead of three
-                    if (NS == 1)
-#endif
-                    acc[nt] = T::mfma(wh, bh, acc[nt]);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) advance();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
-}
-
-// ---- row-window variant with 16-channel stages ---------------------------------------------------------------------------------
-// Same window idea, but a stage is (ky, 16 channels): rows of 32 bytes, half the ring.  At NT = 2 / 3 that lets TWO
-// workgroups share a CU (<= 80 KB each, <= 128 VGPRs): the encoder's convolutions have only K = 576 .. 1152 (a handful of
-// stages), so with one workgroup per CU its prologue (first DMA latency) and epilogue (transpose, 64 .. 96 KB of stores, all
-// CUs in phase) ran with the matrix pipes idle -- measured: dropping 2/3 of the MFMAs or all of the main-loop DMA changed the
-// kernel time by < 15 %.  At NT = 4 (refinement block: 1x5 GRU gates, 3x3 -> 128 / 256) it is what fits the window + KW
-// weight tiles into LDS at all.  Layout: 16-byte chunk c (0 / 1) of row r sits at chunk c ^ ((r >> 3) & 1), which makes the
-// ds_read_b128 lane groups of a 32-row fragment conflict-free; one DMA instruction moves 32 rows.
-template <int NS, int NT, int KW>
-struct ConvRows16Lds {
+// output pixels of one image and, per stage = (ky, 16 channels), stages ONE window of 256 + KW - 1 input rows that serves all
+// KW taps (fragment reads at row offset kx) next to the KW weight tiles: KW x fewer activation DMAs and barriers per MFMA than
+// the generic kernel.  Taps that cross the left / right image border are zeroed per lane at fragment level; rows above /
+// below the image are staged from the zero row.
+// 16-channel stages (rows of 32 bytes) keep the ring small: at NT = 2 / 3 TWO workgroups share a CU (<= 80 KB each, <= 128
+// VGPRs).  The encoder's convolutions have only K = 576 .. 1152, so a lone workgroup's prologue and epilogue (transpose,
+// statistics, 64 .. 96 KB of stores, all CUs in phase) ran with the matrix pipes idle.  At NT = 4 (refinement block: 1x5 GRU
+// gates, 3x3 -> 128 / 256) the small stage is what fits the window + KW weight tiles into LDS at all.  Layout: 16-byte chunk
+// c (0 / 1) of row r sits at chunk c ^ ((r >> 3) & 1), which makes the ds_read_b128 lane groups of a 32-row fragment
+// conflict-free; one DMA instruction moves 32 rows.
+// Measured and dropped (round 1, same-box ABAB of bench.py): 32-channel stages with one workgroup per CU (equal within
+// 1 %); NSLOT = 3 .. 5 ring slots, i.e. 2 .. 4 stages in flight with one workgroup per CU: -5 % end to end -- these
+// kernels are not DMA-latency-bound, the second resident workgroup is worth more than the deeper ring.
+template <int NS, int NT, int KW, int NSLOT>
+struct ConvRowsLds {
     static constexpr int NTE = NT < 2 ? NT : 2;                   // epilogue pass width
     static constexpr int ATILE = 288 * 32;                        // 9 DMA blocks of 32 rows >= 256 + KW - 1
     static constexpr int WTILE = 32 * NT * 32;
     static constexpr int STAGE = NS * (ATILE + KW * WTILE);
     static constexpr int EPI = 8 * 32 * (32 * NTE * 4);
-    static constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    static constexpr int RING = (NSLOT * STAGE > EPI) ? NSLOT * STAGE : EPI;
     static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4;
 };
 
-template <typename T, int NS, int NT, int KW>
-__global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_rows16_kernel(ConvArgs a) {
-    using L = ConvRows16Lds<NS, NT, KW>;
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+__device__ __forceinline__ void conv_wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;       // always safe
+    }
+}
+
+// NSLOT = depth of the staging ring: stage s + NSLOT - 1 is in flight while stage s is multiplied (2 everywhere, see above).
+template <typename T, int NS, int NT, int KW, int NSLOT>
+__global__ __launch_bounds__(512, (NSLOT == 2 && NT < 4 ? 2 : 1)) void conv_rows_kernel(ConvArgs a) {
+    using L = ConvRowsLds<NS, NT, KW, NSLOT>;
     constexpr int ATILE = L::ATILE, WTILE = L::WTILE, STAGE = L::STAGE, RING = L::RING;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -648,10 +537,14 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_rows16_kernel(Conv
         foffa[kx] = r * 32 + ((half ^ ((r >> 3) & 1)) << 4);
     }
 
+    // DMA instructions this wave issues per stage (wave-uniform): what s_waitcnt may leave outstanding
+    int cnt = NS * (1 + (wave == 7 ? 1 : 0));
+#pragma unroll
+    for (int k = 2; k < NPIECE; ++k) cnt += (wave + 8 * (k - 2) < KW * NT) ? NS : 0;
+    constexpr int D = NSLOT - 1;                 // prefetch distance in stages
+
     int ky = 0, cc = 0;                          // position of the NEXT stage to be issued
     set_ky(0);
-#pragma unroll
-    for (int k = 0; k < NPIECE; ++k) stage_piece(k, 0, 0, lds);
     auto advance = [&]() {
         if (++cc == cpt) {
             cc = 0;
@@ -659,19 +552,27 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_rows16_kernel(Conv
             set_ky(ky);
         }
     };
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: stages 0 .. D - 1
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nstage) {
+#pragma unroll
+            for (int k = 0; k < NPIECE; ++k) stage_piece(k, ky, cc, lds + d * STAGE);
+            advance();
+        }
+    conv_wait_vm(nstage >= D ? cnt * (D - 1) : 0);
     __syncthreads();
 
+    int cur_off = 0, nxt_off = D * STAGE;        // ring offsets of the stage being multiplied / being issued
     for (int s = 0; s < nstage; ++s) {
-        unsigned char* cur = lds + (s & 1) * STAGE;
-        unsigned char* nxt = lds + ((s & 1) ^ 1) * STAGE;
-        const bool more = s + 1 < nstage;
+        unsigned char* cur = lds + cur_off;
+        unsigned char* nxt = lds + nxt_off;
+        const bool more = s + D < nstage;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             const unsigned char* wt = cur + NS * ATILE + kx * NS * WTILE;
-            if (more) {                                           // the next stage's pieces, spread over the first KW - 1 taps
+            if (more) {                                           // the pieces of stage s + D, spread over the first KW - 1 taps
                 constexpr int GROUPS = KW - 1;
 #pragma unroll
                 for (int k = 0; k < NPIECE; ++k)
@@ -698,20 +599,14 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_rows16_kernel(Conv
         }
         __builtin_amdgcn_s_setprio(0);
         if (more) advance();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        conv_wait_vm(more ? cnt * (D - 1) : 0);                   // stage s + 1 has landed (the tail drains everything)
         __syncthreads();
+        cur_off = cur_off + STAGE == NSLOT * STAGE ? 0 : cur_off + STAGE;
+        nxt_off = nxt_off + STAGE == NSLOT * STAGE ? 0 : nxt_off + STAGE;
     }
     conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
 }
 
-
-template <int NS, int NT, int KW>
-struct ConvRowsLds {
-    static constexpr int STAGE = NS * (272 * 64 + KW * 32 * NT * 64);
-    static constexpr int EPI = 8 * 32 * (32 * NT * 4);
-    static constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4;
-};
 
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
@@ -732,54 +627,29 @@ static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int NT, int KW>
+template <int NT, int KW, int NSLOT>
 static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stream) {
     static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
     dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
-    constexpr int LDS2 = ConvRowsLds<2, NT, KW>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW>::TOTAL;
+    constexpr int LDS2 = ConvRowsLds<2, NT, KW, NSLOT>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW, NSLOT>::TOTAL;
+    static_assert(LDS2 <= 160 * 1024 && LDS1 <= 160 * 1024, "ring beyond the CU's LDS");
     ScopedKernelTimer timer(UM_K_CONV, stream);
     if (mode == 0) {
         if (!configured[0]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Fp16, 2, NT, KW>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Fp16, 2, NT, KW, NSLOT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
             if (e != hipSuccess) return e;
             configured[0] = true;
         }
-        hipLaunchKernelGGL((conv_rows_kernel<Fp16, 2, NT, KW>), grid, block, LDS2, stream, a);
+        hipLaunchKernelGGL((conv_rows_kernel<Fp16, 2, NT, KW, NSLOT>), grid, block, LDS2, stream, a);
     } else {
         if (!configured[1]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Bf16, 1, NT, KW>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Bf16, 1, NT, KW, NSLOT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
             if (e != hipSuccess) return e;
             configured[1] = true;
         }
-        hipLaunchKernelGGL((conv_rows_kernel<Bf16, 1, NT, KW>), grid, block, LDS1, stream, a);
-    }
-    return hipGetLastError();
-}
-
-template <int NT, int KW>
-static hipError_t launch_conv_rows16(const ConvArgs& a, int mode, hipStream_t stream) {
-    static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
-    dim3 grid(a.B * ((a.Ho * a.Wo + 255) / 256) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
-    constexpr int LDS2 = ConvRows16Lds<2, NT, KW>::TOTAL, LDS1 = ConvRows16Lds<1, NT, KW>::TOTAL;
-    ScopedKernelTimer timer(UM_K_CONV, stream);
-    if (mode == 0) {
-        if (!configured[0]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<Fp16, 2, NT, KW>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-            if (e != hipSuccess) return e;
-            configured[0] = true;
-        }
-        hipLaunchKernelGGL((conv_rows16_kernel<Fp16, 2, NT, KW>), grid, block, LDS2, stream, a);
-    } else {
-        if (!configured[1]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<Bf16, 1, NT, KW>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-            if (e != hipSuccess) return e;
-            configured[1] = true;
-        }
-        hipLaunchKernelGGL((conv_rows16_kernel<Bf16, 1, NT, KW>), grid, block, LDS1, stream, a);
+        hipLaunchKernelGGL((conv_rows_kernel<Bf16, 1, NT, KW, NSLOT>), grid, block, LDS1, stream, a);
     }
     return hipGetLastError();
 }
@@ -811,6 +681,10 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     }
     if (stats_out && !out) {
         um_set_error("um_conv2d: fused statistics need the fp32 output");
+        return -1;
+    }
+    if (bias && ((unsigned long)bias & 15) != 0) {
+        um_set_error("um_conv2d: bias must be 16-byte aligned");
         return -1;
     }
     if (a_rows * a_ld * 2 >= (1L << 32) || (long)cout * kh * kw * cin * 2 >= (1L << 32) || m >= (1L << 31)) {
@@ -857,20 +731,14 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     hipError_t e;
     // widest output tile that does not waste more than a third of its columns
     const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
-    // same-size stride-1 3-tap rows: the row-window kernel (its LDS budget allows 64- and 96-wide output tiles)
+    // same-size stride-1 rows of 3 taps (any tile width) or 5 taps (128-wide tiles: the GRU's 1x5 gates): row-window kernel
     static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
-    const bool rows = kw == 3 && stride == 1 && pad_w == 1 && ho == hi && wo == wi && nt < 4 && (long)ho * wo >= 256 && rows_enabled;
-    // 16-channel-stage row window: UM_CONV_ROWS16 = the tile widths (digits of NT) it may serve, A/B switch read once
-    static const char* rows16_env = getenv("UM_CONV_ROWS16");
-    static const char* rows16_nts = rows16_env ? rows16_env : "234";
     const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;
-    const bool rows16 = same && ((kw == 3 && pad_w == 1) || (kw == 5 && pad_w == 2 && nt == 4)) && strchr(rows16_nts, '0' + nt) != nullptr;
-    if (rows16 && nt == 2) e = launch_conv_rows16<2, 3>(a, mode, (hipStream_t)stream_);
-    else if (rows16 && nt == 3) e = launch_conv_rows16<3, 3>(a, mode, (hipStream_t)stream_);
-    else if (rows16 && nt == 4 && kw == 3) e = launch_conv_rows16<4, 3>(a, mode, (hipStream_t)stream_);
-    else if (rows16 && nt == 4) e = launch_conv_rows16<4, 5>(a, mode, (hipStream_t)stream_);
-    else if (rows && nt == 2) e = launch_conv_rows<2, 3>(a, mode, (hipStream_t)stream_);
-    else if (rows && nt == 3) e = launch_conv_rows<3, 3>(a, mode, (hipStream_t)stream_);
+    const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
+    if (rows3 && nt == 2) e = launch_conv_rows<2, 3, 2>(a, mode, (hipStream_t)stream_);
+    else if (rows3 && nt == 3) e = launch_conv_rows<3, 3, 2>(a, mode, (hipStream_t)stream_);
+    else if (rows3 && nt == 4) e = launch_conv_rows<4, 3, 2>(a, mode, (hipStream_t)stream_);
+    else if (rows5) e = launch_conv_rows<4, 5, 2>(a, mode, (hipStream_t)stream_);
     else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
     else if (nt == 3) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
     else e = launch_conv<2>(a, mode, (hipStream_t)stream_);
@@ -988,6 +856,10 @@ extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, con
     }
     if (stats_out && !out) {
         um_set_error("um_conv7_fwd: fused statistics need the fp32 output");
+        return -1;
+    }
+    if (bias && ((unsigned long)bias & 15) != 0) {
+        um_set_error("um_conv7_fwd: bias must be 16-byte aligned");
         return -1;
     }
     if ((rows + 8) * cpp * 2 >= (1L << 32) || m >= (1L << 31)) {

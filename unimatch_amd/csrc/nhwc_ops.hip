@@ -55,40 +55,49 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* 
 // ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd ---------------------
 // partial[b][part][3][C] = (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short):
 // written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS) or by conv_kernel's epilogue (rpp = 128, k = tile mean).
-// grid (C / 8, B), block 256 = 8 channels x 32 lanes; every lane merges a strided subset of the parts, lane 0 merges the
-// lanes in a fixed order (deterministic).
+// grid (C / 8, B), block 256 = 8 channels x 32 lanes.  Two passes over the (cache-resident) parts, all in fp64 and in a fixed
+// order (deterministic): the mean from the sums, then sum(M2_i + n_i (mean_i - mean)^2) -- the parallel-variance formula
+// with the global mean known, so there is no division inside the loops (the pairwise form needed ~180 fp64 divisions per
+// thread and cost 15 us per launch, 15 launches per forward).
 __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* partial, float* stats, int P, int C, int nparts,
                                                                   int rpp, float eps) {
-    __shared__ double red[3][256];
+    __shared__ double red[256];
+    __shared__ double bc[8];
     const int b = blockIdx.y;
-    const int c = blockIdx.x * 8 + (threadIdx.x & 7), ln = threadIdx.x >> 3;
-    double n_tot = 0.0, mean = 0.0, m2 = 0.0;
+    const int ch = threadIdx.x & 7, c = blockIdx.x * 8 + ch, ln = threadIdx.x >> 3;
+    const int tail = P - (nparts - 1) * rpp;                      // pixels of the last part
+    const double inv_full = 1.0 / (double)rpp, inv_tail = 1.0 / (double)tail;
+    const float* base = partial + ((long)b * nparts * 3) * C + c;
+    double sx = 0.0;
     for (int pt = ln; pt < nparts; pt += 32) {
-        const float* pr = partial + (((long)b * nparts + pt) * 3) * C;
-        const int r0 = pt * rpp;
-        const double n = (double)(min(P, r0 + rpp) - r0);
-        const double k = pr[c], s1 = pr[C + c], s2 = pr[2 * C + c];
-        const double mc = k + s1 / n, m2c = s2 - s1 * s1 / n;
-        const double delta = mc - mean, nn = n_tot + n;
-        mean += delta * n / nn;
-        m2 += m2c + delta * delta * n_tot * n / nn;
-        n_tot = nn;
+        const float* pr = base + (long)pt * 3 * C;
+        const double n = pt == nparts - 1 ? (double)tail : (double)rpp;
+        sx += n * (double)pr[0] + (double)pr[C];                  // sum of x over the part = n k + sum(x - k)
     }
-    red[0][threadIdx.x] = n_tot;
-    red[1][threadIdx.x] = mean;
-    red[2][threadIdx.x] = m2;
+    red[threadIdx.x] = sx;
     __syncthreads();
     if (ln == 0) {
-        for (int l = 1; l < 32; ++l) {
-            const double n = red[0][l * 8 + (threadIdx.x & 7)];
-            if (n == 0.0) continue;
-            const double mc = red[1][l * 8 + (threadIdx.x & 7)], m2c = red[2][l * 8 + (threadIdx.x & 7)];
-            const double delta = mc - mean, nn = n_tot + n;
-            mean += delta * n / nn;
-            m2 += m2c + delta * delta * n_tot * n / nn;
-            n_tot = nn;
-        }
-        const double var = m2 / n_tot;                            // biased, as nn.InstanceNorm2d
+        double t = 0.0;
+        for (int l = 0; l < 32; ++l) t += red[l * 8 + ch];
+        bc[ch] = t / (double)P;
+    }
+    __syncthreads();
+    const double mean = bc[ch];
+    double m2 = 0.0;
+    for (int pt = ln; pt < nparts; pt += 32) {
+        const float* pr = base + (long)pt * 3 * C;
+        const bool last = pt == nparts - 1;
+        const double n = last ? (double)tail : (double)rpp, inv = last ? inv_tail : inv_full;
+        const double k = pr[0], s1 = pr[C], s2 = pr[2 * C];
+        const double d = k + s1 * inv - mean;
+        m2 += (s2 - s1 * s1 * inv) + n * d * d;
+    }
+    red[threadIdx.x] = m2;
+    __syncthreads();
+    if (ln == 0) {
+        double t = 0.0;
+        for (int l = 0; l < 32; ++l) t += red[l * 8 + ch];
+        const double var = t / (double)P;                         // biased, as nn.InstanceNorm2d
         stats[((long)b * 2) * C + c] = (float)mean;
         stats[((long)b * 2 + 1) * C + c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
     }
