@@ -201,13 +201,15 @@ int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, cons
 
 /* nn.InstanceNorm2d (affine=False, biased variance) + ReLU (+ shortcut add + ReLU) of unimatch/backbone.py:7-36 in NHWC:
  *   y = x (normalize == 0) | (x - mean_{b,c}) * rsqrt(var_{b,c} + eps);  y = relu(y) if relu;  y = relu(shortcut + y) if
- * shortcut.  x, shortcut: fp32 [batch*pixels][channels].  Outputs (either may be NULL): operand planes
+ * shortcut.  x, shortcut: fp32 [batch*pixels][channels]; alternatively (shortcut == NULL) shortcut_planes: the shortcut as
+ * operand planes [NS][batch*pixels + 1][channels] (hi + lo is added) -- a residual block's identity shortcut is the planes
+ * its first convolution read, so no fp32 copy of the block input has to exist.  Outputs (either may be NULL): operand planes
  * [NS][batch*pixels + 1][channels] including the zero row um_conv2d_fwd expects, and fp32 [batch*pixels][channels].
  * Statistics are deterministic (fixed reduction order, chunk-shifted sums merged in fp64).  channels: multiple of 8, <= 256. */
 size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channels);
-int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch, int pixels,
-                          int channels, float eps, int normalize, int relu, const float* conv_stats, void* workspace,
-                          size_t workspace_bytes, int mode, void* stream);
+int um_nhwc_instance_norm(const float* x, const float* shortcut, const void* shortcut_planes, void* planes_out, float* f32_out,
+                          int batch, int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats,
+                          void* workspace, size_t workspace_bytes, int mode, void* stream);
 
 /* Channels-last element-wise helpers of the refinement block (SepConvGRU, unimatch/reg_refine.py:55-76); every result is
  * written as operand planes into columns [coff, coff + channels) of a buffer [NS = 2][plane_rows][ld]:

@@ -643,6 +643,11 @@ def test_nhwc_instance_norm(ops, shape):
         pl = planes.view(torch.float16).view(2, rows + 1, c).float()
         assert torch.equal(pl[:, rows], torch.zeros(2, c, device=DEV))              # the padding row
         assert (pl[:, :rows].sum(0) - f32).abs().max().item() < 2e-6 * max(1.0, f32.abs().max().item())
+    # the shortcut handed over as operand planes (what the encoder does for identity shortcuts): hi + lo is added
+    scp, _ = ops.nhwc_norm(scf, b, h * w, normalize=False, relu=False, want_planes=True)
+    _, f32 = ops.nhwc_norm(xf, b, h * w, relu=True, shortcut_planes=scp, want_planes=False, want_f32=True)
+    want = (n64.relu() + sc.double()).relu()
+    assert err(f32.view(b, h, w, c).permute(0, 3, 1, 2), want)[0] < 2e-5
 
 
 @pytest.mark.parametrize('shifted,residual', [(False, True), (True, False)])

@@ -106,11 +106,12 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
 // ---- pass 3: apply.  One thread = 8 channels of one pixel (16 bytes of every output plane).  ----------------------
 //   y = x                          (stats == null: plain format conversion)
 //   y = (x - mean) * rstd          then ReLU if relu
-//   y = relu(shortcut + y)         if shortcut
+//   y = relu(shortcut + y)         if shortcut (fp32) or shortcut_planes (operand planes of the same shape, hi + lo: what the
+//                                  block's first convolution read -- the identity shortcut then needs no fp32 copy in HBM)
 template <typename T, int NS>
 __global__ __launch_bounds__(256) void nhwc_apply_kernel(const float* x, const float* stats, const float* shortcut,
-                                                         unsigned short* planes, float* outf, long rows, int P, int C,
-                                                         int relu) {
+                                                         const unsigned short* shortcut_planes, unsigned short* planes,
+                                                         float* outf, long rows, int P, int C, int relu) {
     const int c8n = C >> 3;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (rows + (planes ? 1 : 0)) * c8n;          // + the zero row of the planes
@@ -152,6 +153,18 @@ __global__ __launch_bounds__(256) void nhwc_apply_kernel(const float* x, const f
         for (int i = 0; i < 4; ++i) {
             v[i] = fmaxf(v[i] + s0[i], 0.f);
             v[4 + i] = fmaxf(v[4 + i] + s1[i], 0.f);
+        }
+    } else if (shortcut_planes) {
+        const u32x4 sh = *reinterpret_cast<const u32x4*>(shortcut_planes + row * C + c);
+        u32x4 sl = {0u, 0u, 0u, 0u};
+        if (NS == 2) sl = *reinterpret_cast<const u32x4*>(shortcut_planes + plane_stride + row * C + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 uh = T::unpack2(sh[i]);
+            f32x2 ul = {0.f, 0.f};
+            if (NS == 2) ul = T::unpack2(sl[i]);
+            v[2 * i] = fmaxf(v[2 * i] + (uh[0] + ul[0]), 0.f);
+            v[2 * i + 1] = fmaxf(v[2 * i + 1] + (uh[1] + ul[1]), 0.f);
         }
     }
     if (outf) {
@@ -280,7 +293,7 @@ extern "C" size_t um_conv_stats_bytes(int batch, int pixels, int channels) {
 
 static bool nhwc_channels_ok(int c) { return c > 0 && c % 8 == 0 && c <= 256; }
 
-extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void* planes_out, float* f32_out, int batch,
+extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, const void* shortcut_planes, void* planes_out, float* f32_out, int batch,
                                      int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats,
                                      void* workspace, size_t workspace_bytes, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -313,10 +326,10 @@ extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, void
     const dim3 grid((unsigned)((total + 255) / 256));
     if (mode == 0)
         hipLaunchKernelGGL((nhwc_apply_kernel<Fp16, 2>), grid, dim3(256), 0, stream, x, stats, shortcut,
-                           (unsigned short*)planes_out, f32_out, rows, pixels, channels, relu);
+                           (const unsigned short*)shortcut_planes, (unsigned short*)planes_out, f32_out, rows, pixels, channels, relu);
     else
         hipLaunchKernelGGL((nhwc_apply_kernel<Bf16, 1>), grid, dim3(256), 0, stream, x, stats, shortcut,
-                           (unsigned short*)planes_out, f32_out, rows, pixels, channels, relu);
+                           (const unsigned short*)shortcut_planes, (unsigned short*)planes_out, f32_out, rows, pixels, channels, relu);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         um_set_error("um_nhwc_instance_norm: launch failed: %s", hipGetErrorString(e));

@@ -6,6 +6,8 @@ Architecture and parameter names follow /root/reference/unimatch/backbone.py:39-
 unimatch/trident_conv.py:10-90 so that reference checkpoints load unchanged
 (``backbone.conv1.weight``, ``backbone.layer2.0.downsample.0.bias``, ``backbone.trident_conv.weight`` ...).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -38,9 +40,10 @@ class _Residual(nn.Module):
 
 
     def forward_nhwc(self, act, ops, want_f32):
-        """Channels-last path on the matrix cores: ``act = (planes, f32, b, h, w, c)`` (operand planes of the block input
-        and, when the shortcut is the identity, its fp32 copy).  Every normalisation kernel writes the next convolution's
-        operand planes directly; ``want_f32`` asks for an fp32 copy of the output as well (identity shortcut downstream)."""
+        """Channels-last path on the matrix cores: ``act = (planes, f32 | None, b, h, w, c)`` (operand planes of the block
+        input).  Every normalisation kernel writes the next convolution's operand planes directly; the identity shortcut is
+        read back from those planes (hi + lo), so no fp32 copy of a block's input exists; ``want_f32`` asks for an fp32 copy
+        of the output as well."""
         planes, f32, b, h, w, c = act
         stride = self.conv1.stride[0]
         cout = self.conv1.out_channels
@@ -48,13 +51,15 @@ class _Residual(nn.Module):
         tp, _ = ops.nhwc_norm(t, b, ho * wo, relu=True, want_planes=True, conv_stats=ops.last_conv_stats)
         u, _, _ = ops.conv2d_nhwc((tp, b, ho, wo, cout), self.conv2.weight, None, 1, (1, 1), stats=True)
         ustats = ops.last_conv_stats
+        sc = scp = None
         if self.downsample is None:
-            sc = f32
+            sc, scp = (f32, None) if f32 is not None else (None, planes)
         else:
             proj = self.downsample[0]
             d, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), proj.weight, proj.bias, stride, (0, 0), stats=True)
             _, sc = ops.nhwc_norm(d, b, ho * wo, relu=False, want_planes=False, want_f32=True, conv_stats=ops.last_conv_stats)
-        op, of = ops.nhwc_norm(u, b, ho * wo, relu=True, shortcut=sc, want_planes=True, want_f32=want_f32, conv_stats=ustats)
+        op, of = ops.nhwc_norm(u, b, ho * wo, relu=True, shortcut=sc, shortcut_planes=scp, want_planes=True, want_f32=want_f32,
+                               conv_stats=ustats)
         return op, of, b, ho, wo, cout
 
 
@@ -131,12 +136,13 @@ class CNNEncoder(nn.Module):
         b = x.shape[0]
         y, h, w = ops.stem_conv(x.contiguous(), self.conv1.weight, input_norm, stats=True)    # fp32 NHWC [b*h*w, 64]
         c = y.shape[1]
-        planes, f32 = ops.nhwc_norm(y, b, h * w, relu=True, want_planes=True, want_f32=True, conv_stats=ops.last_conv_stats)
+        keep_f32 = os.environ.get('UM_SHORTCUT_F32') == '1'      # A/B switch (tools/ab_bench.py): fp32 copies for the shortcuts
+        planes, f32 = ops.nhwc_norm(y, b, h * w, relu=True, want_planes=True, want_f32=keep_f32, conv_stats=ops.last_conv_stats)
         act = (planes, f32, b, h, w, c)
         blocks = [blk for layer in (self.layer1, self.layer2, self.layer3) for blk in layer]
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-            act = blk.forward_nhwc(act, ops, want_f32=nxt is not None and nxt.downsample is None)
+            act = blk.forward_nhwc(act, ops, want_f32=keep_f32 and nxt is not None and nxt.downsample is None)
         planes, _, b, h, w, c = act
         out, _, _ = ops.conv2d_nhwc((planes, b, h, w, c), self.conv2.weight, self.conv2.bias, 1, (0, 0))
         if self.num_branch == 1:

@@ -484,8 +484,9 @@ class HipOps:
         return out, ho, wo
 
     def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5,
-                  conv_stats=None):
-        """InstanceNorm (+ ReLU, + shortcut + ReLU) of fp32 NHWC ``x [b*pixels, c]`` -> ``(planes | None, f32 | None)``."""
+                  conv_stats=None, shortcut_planes=None):
+        """InstanceNorm (+ ReLU, + shortcut + ReLU) of fp32 NHWC ``x [b*pixels, c]`` -> ``(planes | None, f32 | None)``.
+        The shortcut is fp32 ``[b*pixels, c]`` or (``shortcut_planes``) operand planes of the same shape."""
         self._check_rows('x', x, x.shape[1])
         c = x.shape[1]
         if x.shape[0] != b * pixels:
@@ -493,12 +494,15 @@ class HipOps:
         if shortcut is not None:
             self._check_rows('shortcut', shortcut, c)
         rows = b * pixels
+        if shortcut_planes is not None and (shortcut is not None or shortcut_planes.numel() != self.lib.um_planes_bytes(rows + 1, c, self.CONV_MODE)):
+            raise ValueError('nhwc_norm: shortcut_planes must be operand planes of [b * pixels + 1, c] (and exclude shortcut)')
         planes = (torch.empty(self.lib.um_planes_bytes(rows + 1, c, self.CONV_MODE), dtype=torch.uint8, device=x.device)
                   if want_planes else None)
         f32 = torch.empty_like(x) if want_f32 else None
         ws = self._ws(self.lib.um_nhwc_norm_workspace_bytes(b, pixels, c), x.device) if normalize else None
         code = self._launch('instance_norm', lambda: self.lib.um_nhwc_instance_norm(
-            _ptr(x), _ptr(shortcut) if shortcut is not None else None, _ptr(planes) if planes is not None else None,
+            _ptr(x), _ptr(shortcut) if shortcut is not None else None,
+            _ptr(shortcut_planes) if shortcut_planes is not None else None, _ptr(planes) if planes is not None else None,
             _ptr(f32) if f32 is not None else None, b, pixels, c, float(eps), int(bool(normalize)), int(bool(relu)),
             _ptr(conv_stats) if conv_stats is not None else None, _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
         _abi.check(code, 'um_nhwc_instance_norm')
