@@ -219,15 +219,17 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                     for (int i = 0; i < 4; ++i) d[i] = (1.0f - z[i]) * hv[i] + z[i] * d[i];
                     *reinterpret_cast<f32x4*>(hp) = d;
                 }
-                if (to_out) *reinterpret_cast<f32x4*>(obase + (unsigned)(r * a.out_ld + col)) = d;
+                // streaming stores: the tile is next touched by another kernel; as ordinary stores these lines evicted the
+                // activation rows the neighbouring workgroups are about to re-read (+1.5 % end to end, same-box ABAB)
+                if (to_out) __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(obase + (unsigned)(r * a.out_ld + col)));
                 if (to_planes) {
                     unsigned short* dst = pbase + (unsigned)(r * a.outp_ld + col);
                     const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};     // planes feed the next convolution: ordinary stores
                     if (NS == 2) {
                         const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                        *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) =
-                            u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                        const u32x2 lo = u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                        *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) = lo;
                     }
                 }
             }

@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void nhwc_apply_kernel(const float* x, const f
     }
     float v[8];
     {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + row * C + c);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + row * C + c + 4);
+        // x is read exactly once: streaming loads (the output planes are re-read by the next convolution: ordinary stores)
+        const f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * C + c));
+        const f32x4 a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * C + c + 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = a0[i];
