@@ -621,7 +621,8 @@ def test_conv2d_ex_random_geometries(ops, case):
     assert err(got, want)[0] < 3e-6 * max(1.0, pre.abs().max().item()), case
 
 
-@pytest.mark.parametrize('shape', [(2, 64, 37, 29), (1, 96, 64, 48), (3, 128, 5, 7)])
+@pytest.mark.parametrize('shape', [(2, 64, 37, 29), (1, 96, 64, 48), (3, 128, 5, 7),
+                                   (1, 8, 520, 512)])      # > 1024 statistics parts per image: the two-pass merge
 def test_nhwc_instance_norm(ops, shape):
     """NHWC InstanceNorm (+ ReLU, + shortcut + ReLU) against fp64, both output formats; a large mean exercises the
     shifted statistics.  Planes are checked by summing hi + lo."""

@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* 
 // ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd ---------------------
 // partial[b][part][3][C] = (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short):
 // written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS) or by conv_kernel's epilogue (rpp = 128, k = tile mean).
-// grid (C / 8, B), block 256 = 8 channels x 32 lanes.  Two passes over the (cache-resident) parts, all in fp64 and in a fixed
-// order (deterministic): the mean from the sums, then sum(M2_i + n_i (mean_i - mean)^2) -- the parallel-variance formula
-// with the global mean known, so there is no division inside the loops (the pairwise form needed ~180 fp64 divisions per
-// thread and cost 15 us per launch, 15 launches per forward).
+// grid (C / 8, B), block 256 = 8 channels x 32 lanes.  All in fp64 and in a fixed order (deterministic): the mean from the
+// sums, then sum(M2_i + n_i (mean_i - mean)^2) -- the parallel-variance formula with the global mean known, so there is no
+// division inside the loops.  The parts were written by other XCDs (a microsecond away): up to 1024 parts per image every
+// lane loads ALL its parts in one batch and keeps them in registers for the second sum, so the kernel costs about one
+// memory round trip (it is launched 15 times per forward); larger images take two batched passes over memory.
 __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* partial, float* stats, int P, int C, int nparts,
                                                                   int rpp, float eps) {
     __shared__ double red[256];
@@ -68,11 +69,33 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
     const int tail = P - (nparts - 1) * rpp;                      // pixels of the last part
     const double inv_full = 1.0 / (double)rpp, inv_tail = 1.0 / (double)tail;
     const float* base = partial + ((long)b * nparts * 3) * C + c;
+    constexpr int NB = 32;                                        // parts per lane held in registers
+    const bool in_regs = nparts <= 32 * NB;
+    float rk[NB], r1[NB], r2[NB];
     double sx = 0.0;
-    for (int pt = ln; pt < nparts; pt += 32) {
-        const float* pr = base + (long)pt * 3 * C;
-        const double n = pt == nparts - 1 ? (double)tail : (double)rpp;
-        sx += n * (double)pr[0] + (double)pr[C];                  // sum of x over the part = n k + sum(x - k)
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int pt = ln + 32 * j;
+            rk[j] = r1[j] = r2[j] = 0.f;
+            if (pt < nparts) {
+                const float* pr = base + (long)pt * 3 * C;
+                rk[j] = pr[0];
+                r1[j] = pr[C];
+                r2[j] = pr[2 * C];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int pt = ln + 32 * j;
+            if (pt < nparts) sx += (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)rk[j] + (double)r1[j];
+        }
+    } else {
+#pragma unroll 8
+        for (int pt = ln; pt < nparts; pt += 32) {
+            const float* pr = base + (long)pt * 3 * C;
+            sx += (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)pr[0] + (double)pr[C];   // sum of x = n k + sum(x - k)
+        }
     }
     red[threadIdx.x] = sx;
     __syncthreads();
@@ -84,13 +107,24 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
     __syncthreads();
     const double mean = bc[ch];
     double m2 = 0.0;
-    for (int pt = ln; pt < nparts; pt += 32) {
-        const float* pr = base + (long)pt * 3 * C;
+    auto add_part = [&](int pt, double k, double s1, double s2) {
         const bool last = pt == nparts - 1;
         const double n = last ? (double)tail : (double)rpp, inv = last ? inv_tail : inv_full;
-        const double k = pr[0], s1 = pr[C], s2 = pr[2 * C];
         const double d = k + s1 * inv - mean;
         m2 += (s2 - s1 * s1 * inv) + n * d * d;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int pt = ln + 32 * j;
+            if (pt < nparts) add_part(pt, rk[j], r1[j], r2[j]);
+        }
+    } else {
+#pragma unroll 8
+        for (int pt = ln; pt < nparts; pt += 32) {
+            const float* pr = base + (long)pt * 3 * C;
+            add_part(pt, pr[0], pr[C], pr[2 * C]);
+        }
     }
     red[threadIdx.x] = m2;
     __syncthreads();
