@@ -9,7 +9,8 @@ neighbours), so every optimisation of round 1 was accepted or dropped on an ABAB
 
 Every argument is `label=ENV1=v1,ENV2=v2` (empty = the tree as it is).  Useful switches: `UM_LIB` (an alternative build of
 the library, e.g. compiled with a -D flag into unimatch_amd/_variants/), `UM_NO_MERGE=1` (merge + LayerNorm as its own
-launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only).  Run-to-run repeatability on one box is ~0.1 %.
+launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only), `UM_CONV_NO_XCD=1` (plain workgroup order in the convolutions),
+`UM_SHORTCUT_F32=1` (encoder keeps fp32 copies for the identity shortcuts).  Run-to-run repeatability on one box is ~0.1 %.
 """
 import json
 import os
