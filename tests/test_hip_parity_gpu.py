@@ -408,6 +408,11 @@ def _nhwc_planes(ops, x_nchw):
     (2, 256, 128, 18, 15, 1, 5, 1, 0, 2, True, False),       # GRU 1x5 gate shape: five-tap row window
     (1, 256, 256, 9, 40, 1, 5, 1, 0, 2, True, False),        # GRU z|r shape, rows longer than the taps reach
     (1, 64, 64, 33, 65, 3, 3, 1, 1, 1, True, True),          # NT = 2 row window, 9 tiles with a ragged tail
+    (2, 64, 64, 16, 64, 3, 3, 1, 1, 1, False, False),        # 2-D patch kernel: 2 x 2 tiles per image, two images
+    (1, 64, 36, 8, 32, 3, 3, 1, 1, 1, True, True),           # patch kernel, a single tile (all four borders), ragged cout
+    (1, 96, 64, 24, 96, 3, 3, 1, 1, 1, True, False),         # patch kernel, six channel chunks, 3 x 3 tiles (an interior one)
+    (1, 128, 128, 24, 32, 3, 3, 1, 1, 1, False, True),       # patch kernel NT = 4
+    (2, 128, 256, 8, 64, 3, 3, 1, 1, 1, True, True),         # patch kernel NT = 4, two output tiles
 ])
 def test_conv2d_nhwc_matches_fp64(ops, case):
     """um_conv2d_fwd (implicit GEMM on split-fp16 planes) against torch conv2d in fp64: every kernel geometry the
@@ -446,10 +451,11 @@ def test_cost_volume_planes_equal_the_volume(ops):
         assert torch.equal(pl[:, rows], torch.zeros(2, 96, device=DEV))
 
 
-def test_conv_ex_offsets_and_gates(ops):
+@pytest.mark.parametrize('hw', [(9, 11), (16, 32)])                # generic kernel; 2-D patch kernel (whole 8 x 32 tiles)
+def test_conv_ex_offsets_and_gates(ops, hw):
     """um_conv2d_ex reading a column slice and writing planes at a column offset (the block's concat-free chaining), and
     the three um_nhwc_gate modes against plain tensor arithmetic."""
-    b, h, w, cin, cout = 2, 9, 11, 64, 128
+    b, (h, w), cin, cout = 2, hw, 64, 128
     rows = b * h * w
     x = rnd(123, rows, 96)                                                       # the conv reads columns 32..96 of this
     wt = rnd(124, cout, cin, 3, 3, scale=0.05)
@@ -560,6 +566,8 @@ def test_stem_conv_matches_fp64(ops, bhw, normalize):
                                             (128, (19, 23), 1),       # NT = 4: generic kernel, 437 pixels
                                             (96, (7, 9), 1),          # 63 pixels: a single partial tile per image
                                             (96, (21, 30), 2),        # stride 2 -> 11 x 15 = 165 pixels
+                                            (64, (16, 64), 1),        # 2-D patch kernel: parts in tile order
+                                            (128, (24, 32), 1),       # patch kernel NT = 4
                                             (64, (47, 63), 2)])       # KITTI-like odd map
 def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw, stride):
     """um_conv2d_fwd(stats_out) -> um_nhwc_instance_norm(conv_stats): the per-tile statistics written by the convolution's

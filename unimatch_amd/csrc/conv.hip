@@ -17,6 +17,7 @@
 // Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
 // computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "planes.h"
 
@@ -60,7 +61,8 @@ __device__ __forceinline__ void conv_dma16(const void* base, unsigned byte_off, 
                  : "memory");
 }
 
-// ---- epilogue shared by both kernels: lane holds, for pixel pl0 + 32*wave + (lane & 31) of image bt, outputs
+// ---- epilogue shared by all kernels: lane holds, for pixel rloc0 + (lane & 31) of image bt (rloc0 = the wave's first pixel,
+// nvalid <= 32 of its pixels exist; part0 = statistics part of the workgroup's first four waves), outputs
 // n0 + 32*nt + 8*g + 4*half + i (reg 4*g + i).  Output tiles never straddle images (the last tile of an image is ragged).  `scratch` = LDS beyond the (now
 // idle) staging ring: 2 * 32 NT floats per wave for the statistics.  One pass handles the n-tiles [NT0, NT0 + NTP) of the
 // wave's NT (the transposed tile of a pass must fit the ring: conv_epilogue below picks the pass width).
@@ -71,7 +73,8 @@ struct IntC {
 
 template <typename T, int NS, int NT, int NT0, int NTP, int WSTRIDE>   // WSTRIDE: bytes of a wave's private staging block
 __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                                   int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
+                                                   int bt, int rloc0, int nvalid, int part0, int n0, int tid, int wave, int lane,
+                                                   int half) {
     const int P = a.Ho * a.Wo;                                    // pixels per image
     // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NTP block; 16-byte chunk c of
     // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
@@ -115,7 +118,6 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
     }
     __builtin_amdgcn_wave_barrier();
     constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
-    const int rloc0 = pl0 + 32 * wave;                            // first pixel of this wave inside the image
     if (a.stats) {
         // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
         // Per wave: its valid pixels (32 except in the ragged last tile of an image), shifted by the first one (no
@@ -123,7 +125,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         // 128 pixels are merged with the parallel-variance formula; um_nhwc_instance_norm merges the tiles (in fp64).
         constexpr int RG = 64 / CPR >= 8 ? 8 : 64 / CPR >= 4 ? 4 : 2;       // row groups (lanes beyond RG * CPR idle)
         constexpr int RPG = 32 / RG;
-        const int nv = min(32, max(0, P - rloc0));
+        const int nv = nvalid;
         const int c = lane % CPR, rg = lane / CPR;
         const f32x4 k = *reinterpret_cast<const f32x4*>(stg + (c << 4));                     // row 0 (chunk c ^ 0)
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -155,6 +157,8 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                 s2[i] += __shfl_down(s2[i], step, 64);
             }
         float* ws = reinterpret_cast<float*>(scratch) + wave * (2 * 32 * NT) + 32 * NT0;
+        float* cnt = reinterpret_cast<float*>(scratch) + 8 * (2 * 32 * NT);             // valid pixels per wave
+        if (lane == 0) cnt[wave] = (float)nv;
         if (lane < CPR) {
             const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
             *reinterpret_cast<f32x4*>(ws + 4 * c) = k + s1 * inv;                            // mean of the wave's valid pixels
@@ -163,13 +167,13 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         __syncthreads();
         // threads 0 .. 32 NTP - 1 of every group of four waves merge that group's 128 pixels
         const int grp = tid >> 8, gt = tid & 255;
-        if (gt < 32 * NTP && nb + gt < a.Cout && pl0 + 128 * grp < P) {
+        if (gt < 32 * NTP && nb + gt < a.Cout && cnt[4 * grp] > 0.f) {       // a group's first wave has pixels if any has
             const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT) + 32 * NT0;
             float mean = w0[gt], m2 = w0[32 * NT + gt];
-            float n = (float)min(32, P - (pl0 + 128 * grp));                 // wave 0 of the group always has valid pixels
+            float n = cnt[4 * grp];
 #pragma unroll
             for (int wv = 1; wv < 4; ++wv) {
-                const float nw = (float)min(32, max(0, P - (pl0 + 128 * grp + 32 * wv)));
+                const float nw = cnt[4 * grp + wv];
                 if (nw > 0.f) {
                     const float mw = w0[wv * (2 * 32 * NT) + gt], m2w = w0[wv * (2 * 32 * NT) + 32 * NT + gt];
                     const float delta = mw - mean, nn = n + nw;
@@ -178,8 +182,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                     n = nn;
                 }
             }
-            const int tiles128 = (P + 127) / 128;                           // statistics parts per image
-            float* pr = a.stats + ((long)(bt * tiles128 + pl0 / 128 + grp) * 3) * a.Cout + nb + gt;
+            float* pr = a.stats + ((long)(part0 + grp) * 3) * a.Cout + nb + gt;
             pr[0] = mean;
             pr[a.Cout] = 0.f;
             pr[2 * a.Cout] = m2;
@@ -188,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
     // ---- full-row stores: wave-uniform 64-bit bases, 32-bit lane offsets
     constexpr int ITER = 32 * CPR / 64;
     const long rowbase = (long)bt * P + rloc0;                    // first output row of this wave
-    const int nrows = min(32, P - rloc0);                         // valid rows (<= 0: none)
+    const int nrows = nvalid;                                     // valid rows (0: none)
     auto store_rows = [&](auto gate_tag) {
         constexpr int GATE = decltype(gate_tag)::value;
         float* obase = a.out ? a.out + rowbase * a.out_ld + a.out_coff : nullptr;
@@ -243,12 +246,14 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
 // NTE = n-tiles per epilogue pass (NT: the whole tile at once).
 template <typename T, int NS, int NT, int NTE = NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                              int bt, int pl0, int n0, int tid, int wave, int lane, int half) {
+                                              int bt, int rloc0, int nvalid, int part0, int n0, int tid, int wave, int lane,
+                                              int half) {
     constexpr int NP = NTE < NT ? NTE : NT;
     constexpr int WSTRIDE = 32 * (32 * NP * 4);
-    conv_epilogue_pass<T, NS, NT, 0, NP, WSTRIDE>(a, acc, lds, scratch, bt, pl0, n0, tid, wave, lane, half);
+    conv_epilogue_pass<T, NS, NT, 0, NP, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, n0, tid, wave, lane, half);
     if constexpr (NTE < NT)          // the wave's staging block is private and DS operations of a wave execute in order
-        conv_epilogue_pass<T, NS, NT, NTE, NT - NTE, WSTRIDE>(a, acc, lds, scratch, bt, pl0, n0, tid, wave, lane, half);
+        conv_epilogue_pass<T, NS, NT, NTE, NT - NTE, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, n0, tid, wave, lane,
+                                                              half);
 }
 
 template <typename T, int NS, int NT>
@@ -258,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     constexpr int STAGE = NS * (TILE + WTILE);   // activation planes then weight planes (NT = 2: 48 KB ring -> 3 WG / CU)
     constexpr int EPI = 4 * 32 * (32 * NT * 4);   // the epilogue's transposed tile
     constexpr int RING = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 4 * 2 * 32 * NT * 4];   // + per-wave (mean, M2) columns
+    // + per-wave (mean, M2) columns at the stride of 8 waves + per-wave pixel counts (the epilogue's scratch layout)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 8 * 2 * 32 * NT * 4 + 64];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,7 +393,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
+    {
+        const int rloc0 = pl0 + 32 * wave;
+        conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, rloc0, min(32, max(0, P - rloc0)), bt * ((P + 127) / 128) + pl0 / 128, n0, tid,
+                                 wave, lane, half);
+    }
 }
 
 // ---- row-window variant: same-size stride-1 convolutions with KW = 3 / 5 horizontal taps -------------------------------------
@@ -415,7 +425,7 @@ struct ConvRowsLds {
     static constexpr int STAGE = NS * (ATILE + KW * WTILE);
     static constexpr int EPI = 8 * 32 * (32 * NTE * 4);
     static constexpr int RING = (NSLOT * STAGE > EPI) ? NSLOT * STAGE : EPI;
-    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4;
+    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4 + 64;   // + statistics scratch: (mean, M2) columns and pixel counts per wave
 };
 
 // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
@@ -606,9 +616,158 @@ __global__ __launch_bounds__(512, (NSLOT == 2 && NT < 4 ? 2 : 1)) void conv_rows
         cur_off = cur_off + STAGE == NSLOT * STAGE ? 0 : cur_off + STAGE;
         nxt_off = nxt_off + STAGE == NSLOT * STAGE ? 0 : nxt_off + STAGE;
     }
-    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, pl0, n0, tid, wave, lane, half);
+    {
+        const int rloc0 = pl0 + 32 * wave;
+        conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, rloc0, min(32, max(0, P - rloc0)), bt * ((P + 127) / 128) + pl0 / 128,
+                                         n0, tid, wave, lane, half);
+    }
 }
 
+
+// ---- 2-D patch variant: 3x3 / stride 1 / pad 1 on maps whose height is a multiple of 8 and width a multiple of 32 -------------
+// The row-window kernel still stages a tile's activations once per kernel ROW: three windows, image-row-length apart, that a
+// 4 MB L2 shared by 64 resident tiles does not keep (1.3 GB fetched per launch for 0.4 GB of input at 256 x 384 x 16).  Here
+// the tile is 8 rows x 32 columns and its (8 + 2) x (32 + 2) halo patch is staged ONCE per 16-channel chunk and serves all
+// nine taps: wave w = tile row w, lane = column, tap (ky, kx) reads patch pixel (w + ky) * 34 + kx + lane -- 32 consecutive
+// 32-byte rows at any offset, conflict-free with the chunk c ^ ((r >> 3) & 1) layout.  2.5x fewer activation bytes through
+// L2 / LDS-DMA, no tap masks, no per-row index arithmetic (out-of-image patch pixels point at the zero row once).  Stages are
+// (chunk, kernel row): the patch is double-buffered per chunk, the three weight tiles of a kernel row per stage; <= 80 KB at
+// NT = 2 so two workgroups share a CU.  With H % 8 == 0 and W % 32 == 0 every statistics part is a full 128 pixels.
+template <int NS, int NT>
+struct ConvPatchLds {
+    static constexpr int NTE = NT < 2 ? NT : 2;
+    static constexpr int PW = 34, PPIX = 10 * PW;                 // patch: 10 x 34 pixels
+    static constexpr int PROWS = 352;                             // 11 DMA blocks of 32 patch pixels
+    static constexpr int ATILE = PROWS * 32;                      // one plane of the patch (16 channels)
+    static constexpr int WTILE = 32 * NT * 32;                    // one plane of one tap's weight tile
+    static constexpr int ASLOT = NS * ATILE, WSLOT = NS * 3 * WTILE;
+    static constexpr int WBASE = 2 * ASLOT;
+    static constexpr int STAGES = 2 * ASLOT + 2 * WSLOT;
+    static constexpr int EPI = 8 * 32 * (32 * NTE * 4);
+    static constexpr int RING = (STAGES > EPI) ? STAGES : EPI;
+    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4 + 64;
+};
+
+template <typename T, int NS, int NT>
+__global__ __launch_bounds__(512, (NT < 3 ? 2 : 1)) void conv_patch_kernel(ConvArgs a) {
+    using L = ConvPatchLds<NS, NT>;
+    constexpr int ATILE = L::ATILE, WTILE = L::WTILE, ASLOT = L::ASLOT, WSLOT = L::WSLOT, WBASE = L::WBASE, RING = L::RING;
+    constexpr int PW = L::PW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, fr = lane & 31;
+    const int P = a.Ho * a.Wo, twn = a.Wo >> 5, tpi = twn * (a.Ho >> 3);        // tiles per row / per image
+    const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);           // 1-D XCD-aware grid, see conv_kernel
+    const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = wg / ny;
+    const int bt = tile / tpi, tt = tile - bt * tpi;
+    const int ty = tt / twn, tx = tt - ty * twn;
+    const int y0 = ty * 8, x0 = tx * 32;
+    const int n0 = (wg - tile * ny) * (32 * NT);
+    const int cpt = a.Cin >> 4;                  // 16-channel chunks
+    const int ktot = 9 * a.Cin;
+
+    // ---- patch pixels this lane stages: DMA block blk = wave (and 8 + wave for waves 0..2), pixel j = 32 blk + (lane >> 1)
+    const int dcp = lane & 1;
+    unsigned rowoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = 32 * (wave + 8 * i) + (lane >> 1);
+        const int py = j / PW, px = j - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = j < L::PPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+        const unsigned row = ok ? (unsigned)((bt * a.Hi + iy) * a.Wi + ix) : a.zero_row;
+        rowoff[i] = row * a.row_stride;
+    }
+    auto stage_patch = [&](int cc, unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (i == 0 || wave < 3) {
+                const int blk = wave + 8 * i;
+                const int r = 32 * blk + (lane >> 1);
+                const int sc = dcp ^ ((r >> 3) & 1);
+                const unsigned off = rowoff[i] + (unsigned)((cc * 16 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) conv_dma16(a.ap + pl * a.a_plane_stride, off, buf + pl * ATILE + (32 * blk) * 32);
+            }
+    };
+    // the three weight tiles of kernel row ky: 3 NT blocks of 32 output rows, block q = (tap kx, rows 32 jb ..)
+    auto stage_w = [&](int cc, int ky, unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < (3 * NT + 7) / 8; ++k) {
+            const int q = wave + 8 * k;
+            if (q < 3 * NT) {
+                const int kx = q / NT, jb = q - kx * NT;
+                const int r = 32 * jb + (lane >> 1);
+                const int sc = dcp ^ ((r >> 3) & 1);
+                const int n = min(n0 + r, a.Cout - 1);
+                const unsigned off = (unsigned)(((long)n * ktot + (ky * 3 + kx) * a.Cin + cc * 16 + 8 * sc) * 2);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    conv_dma16(a.wp + pl * a.w_plane_stride, off, buf + (kx * NS + pl) * WTILE + (32 * jb) * 32);
+            }
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // fragment offsets: weights row fr; activations patch pixel (wave + ky) * 34 + kx + fr
+    const int foffw = fr * 32 + ((half ^ ((fr >> 3) & 1)) << 4);
+    int foffa[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int r = (wave + ky) * PW + kx + fr;
+            foffa[ky][kx] = r * 32 + ((half ^ ((r >> 3) & 1)) << 4);
+        }
+
+    stage_patch(0, lds);
+    stage_w(0, 0, lds + WBASE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int cc = 0; cc < cpt; ++cc) {
+        const int a_cur = (cc & 1) * ASLOT, a_nxt = ASLOT - a_cur;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int w_par = (cc + ky) & 1;                      // stage index 3 cc + ky has the parity of cc + ky
+            const int w_cur = WBASE + w_par * WSLOT, w_nxt = WBASE + (w_par ^ 1) * WSLOT;
+            const bool last = ky == 2 && cc + 1 == cpt;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                if (kx == 0 && !last) stage_w(ky == 2 ? cc + 1 : cc, ky == 2 ? 0 : ky + 1, lds + w_nxt);
+                if (kx == 1 && ky == 0 && cc + 1 < cpt) stage_patch(cc + 1, lds + a_nxt);     // used from stage (cc + 1, 0) on
+                const i16x8 bh = *reinterpret_cast<const i16x8*>(lds + a_cur + foffa[ky][kx]);
+                i16x8 bl;
+                if (NS == 2) bl = *reinterpret_cast<const i16x8*>(lds + a_cur + ATILE + foffa[ky][kx]);
+                const unsigned char* wt = lds + w_cur + kx * NS * WTILE;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 32 + foffw);
+                    if (NS == 2) {
+                        const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 32 + foffw);
+                        acc[nt] = T::mfma(wl, bh, acc[nt]);
+                        acc[nt] = T::mfma(wh, bl, acc[nt]);
+                    }
+                    acc[nt] = T::mfma(wh, bh, acc[nt]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, (y0 + wave) * a.Wo + x0, 32, bt * (P >> 7) + 2 * tt, n0, tid, wave,
+                                     lane, half);
+}
 
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
@@ -652,6 +811,33 @@ static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stre
             configured[1] = true;
         }
         hipLaunchKernelGGL((conv_rows_kernel<Bf16, 1, NT, KW, NSLOT>), grid, block, LDS1, stream, a);
+    }
+    return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_conv_patch(const ConvArgs& a, int mode, hipStream_t stream) {
+    static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
+    dim3 grid(a.B * (a.Ho / 8) * (a.Wo / 32) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
+    constexpr int LDS2 = ConvPatchLds<2, NT>::TOTAL, LDS1 = ConvPatchLds<1, NT>::TOTAL;
+    static_assert(LDS2 <= 160 * 1024 && LDS1 <= 160 * 1024, "ring beyond the CU's LDS");
+    ScopedKernelTimer timer(UM_K_CONV, stream);
+    if (mode == 0) {
+        if (!configured[0]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Fp16, 2, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            if (e != hipSuccess) return e;
+            configured[0] = true;
+        }
+        hipLaunchKernelGGL((conv_patch_kernel<Fp16, 2, NT>), grid, block, LDS2, stream, a);
+    } else {
+        if (!configured[1]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Bf16, 1, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            if (e != hipSuccess) return e;
+            configured[1] = true;
+        }
+        hipLaunchKernelGGL((conv_patch_kernel<Bf16, 1, NT>), grid, block, LDS1, stream, a);
     }
     return hipGetLastError();
 }
@@ -737,7 +923,13 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
     const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;
     const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
-    if (rows3 && nt == 2) e = launch_conv_rows<2, 3, 2>(a, mode, (hipStream_t)stream_);
+    // 3x3 on maps made of whole 8 x 32 tiles: the 2-D patch kernel (UM_CONV_PATCH = the tile widths it may serve, A/B switch)
+    static const char* patch_env = getenv("UM_CONV_PATCH");
+    static const char* patch_nts = patch_env ? patch_env : "24";
+    const bool patch = rows3 && kh == 3 && pad_h == 1 && hi % 8 == 0 && wi % 32 == 0 && strchr(patch_nts, '0' + nt) != nullptr;
+    if (patch && nt == 2) e = launch_conv_patch<2>(a, mode, (hipStream_t)stream_);
+    else if (patch && nt == 4) e = launch_conv_patch<4>(a, mode, (hipStream_t)stream_);
+    else if (rows3 && nt == 2) e = launch_conv_rows<2, 3, 2>(a, mode, (hipStream_t)stream_);
     else if (rows3 && nt == 3) e = launch_conv_rows<3, 3, 2>(a, mode, (hipStream_t)stream_);
     else if (rows3 && nt == 4) e = launch_conv_rows<4, 3, 2>(a, mode, (hipStream_t)stream_);
     else if (rows5) e = launch_conv_rows<4, 5, 2>(a, mode, (hipStream_t)stream_);
