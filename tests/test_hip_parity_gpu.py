@@ -412,6 +412,7 @@ def _nhwc_planes(ops, x_nchw):
     (1, 64, 36, 8, 32, 3, 3, 1, 1, 1, True, True),           # patch kernel, a single tile (all four borders), ragged cout
     (1, 96, 64, 24, 96, 3, 3, 1, 1, 1, True, False),         # patch kernel, six channel chunks, 3 x 3 tiles (an interior one)
     (1, 128, 128, 24, 32, 3, 3, 1, 1, 1, False, True),       # patch kernel NT = 4
+    (2, 96, 96, 16, 32, 3, 3, 1, 1, 1, True, True),          # patch kernel NT = 3 (epilogue in two passes)
     (2, 128, 256, 8, 64, 3, 3, 1, 1, 1, True, True),         # patch kernel NT = 4, two output tiles
 ])
 def test_conv2d_nhwc_matches_fp64(ops, case):
@@ -568,6 +569,7 @@ def test_stem_conv_matches_fp64(ops, bhw, normalize):
                                             (96, (21, 30), 2),        # stride 2 -> 11 x 15 = 165 pixels
                                             (64, (16, 64), 1),        # 2-D patch kernel: parts in tile order
                                             (128, (24, 32), 1),       # patch kernel NT = 4
+                                            (96, (16, 64), 1),        # patch kernel NT = 3
                                             (64, (47, 63), 2)])       # KITTI-like odd map
 def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw, stride):
     """um_conv2d_fwd(stats_out) -> um_nhwc_instance_norm(conv_stats): the per-tile statistics written by the convolution's

@@ -644,14 +644,14 @@ struct ConvPatchLds {
     static constexpr int WBASE = 2 * ASLOT;
     static constexpr int STAGES = 2 * ASLOT + 2 * WSLOT;
     static constexpr int EPI = 8 * 32 * (32 * NTE * 4);
-    static constexpr int RING = (STAGES > EPI) ? STAGES : EPI;
-    static constexpr int TOTAL = RING + 8 * 2 * 32 * NT * 4 + 64;
-};
+    static constexpr int SCRATCH = 8 * 2 * 32 * NT * 4 + 64;      // the epilogue's statistics scratch sits behind its transposed
+    static constexpr int TOTAL = (STAGES > EPI + SCRATCH) ? STAGES : EPI + SCRATCH;   // tile, inside the then idle staging area:
+};                                                                // NT = 3 is exactly 80 KB, two workgroups fill the CU's LDS
 
 template <typename T, int NS, int NT>
-__global__ __launch_bounds__(512, (NT < 3 ? 2 : 1)) void conv_patch_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_patch_kernel(ConvArgs a) {
     using L = ConvPatchLds<NS, NT>;
-    constexpr int ATILE = L::ATILE, WTILE = L::WTILE, ASLOT = L::ASLOT, WSLOT = L::WSLOT, WBASE = L::WBASE, RING = L::RING;
+    constexpr int ATILE = L::ATILE, WTILE = L::WTILE, ASLOT = L::ASLOT, WSLOT = L::WSLOT, WBASE = L::WBASE;
     constexpr int PW = L::PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(512, (NT < 3 ? 2 : 1)) void conv_patch_kernel(ConvA
             __syncthreads();
         }
     }
-    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, (y0 + wave) * a.Wo + x0, 32, bt * (P >> 7) + 2 * tt, n0, tid, wave,
+    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + L::EPI, bt, (y0 + wave) * a.Wo + x0, 32, bt * (P >> 7) + 2 * tt, n0, tid, wave,
                                      lane, half);
 }
 
@@ -925,9 +925,10 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
     // 3x3 on maps made of whole 8 x 32 tiles: the 2-D patch kernel (UM_CONV_PATCH = the tile widths it may serve, A/B switch)
     static const char* patch_env = getenv("UM_CONV_PATCH");
-    static const char* patch_nts = patch_env ? patch_env : "24";
+    static const char* patch_nts = patch_env ? patch_env : "234";
     const bool patch = rows3 && kh == 3 && pad_h == 1 && hi % 8 == 0 && wi % 32 == 0 && strchr(patch_nts, '0' + nt) != nullptr;
     if (patch && nt == 2) e = launch_conv_patch<2>(a, mode, (hipStream_t)stream_);
+    else if (patch && nt == 3) e = launch_conv_patch<3>(a, mode, (hipStream_t)stream_);
     else if (patch && nt == 4) e = launch_conv_patch<4>(a, mode, (hipStream_t)stream_);
     else if (rows3 && nt == 2) e = launch_conv_rows<2, 3, 2>(a, mode, (hipStream_t)stream_);
     else if (rows3 && nt == 3) e = launch_conv_rows<3, 3, 2>(a, mode, (hipStream_t)stream_);
