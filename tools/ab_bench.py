@@ -9,7 +9,7 @@ neighbours), so every optimisation of round 1 was accepted or dropped on an ABAB
 
 Every argument is `label=ENV1=v1,ENV2=v2` (empty = the tree as it is).  Useful switches: `UM_LIB` (an alternative build of
 the library, e.g. compiled with a -D flag into unimatch_amd/_variants/), `UM_NO_MERGE=1` (merge + LayerNorm as its own
-launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only), `UM_CONV_NO_XCD=1` (plain workgroup order in the convolutions),
+launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only), `UM_CONV_NO_XCD=1` (plain workgroup order in the convolutions), `UM_CONV_PATCH=0` (no 2-D patch kernel; digits = tile widths it may serve),
 `UM_SHORTCUT_F32=1` (encoder keeps fp32 copies for the identity shortcuts).  Run-to-run repeatability on one box is ~0.1 %.
 """
 import json
