@@ -174,10 +174,13 @@ int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long
                       float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld, void* out_planes, int outp_ld,
                       int outp_coff, long outp_rows, int batch, int hi, int wi, int cin, int channels, int kh, int kw, int pad_h,
                       int pad_w, int wshift, int mode, void* stream);
-/* stats_out (optional, um_conv_stats_bytes() bytes): per 128-pixel output tile of every image (the last one may be
- * ragged) the (mean, 0, sum of squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway; pass it to
- * um_nhwc_instance_norm(conv_stats) and the normalisation skips its own statistics pass over the activation. */
-size_t um_conv_stats_bytes(int batch, int pixels, int channels);
+/* stats_out (optional): per output tile part (<= 128 pixels, in the order of the serving kernel's tiles) the (mean, pixel
+ * count, sum of squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway.
+ * um_conv_stats_parts() = parts per image for that geometry (the stem, um_conv7_fwd / um_stem_conv_fwd: kh = kw = 7,
+ * stride 2, pad 3); the buffer holds um_conv_stats_bytes(batch, parts, cout) bytes; pass both to
+ * um_nhwc_instance_norm(conv_stats, conv_stats_parts) and the normalisation skips its own statistics pass. */
+int um_conv_stats_parts(int hi, int wi, int cout, int kh, int kw, int stride, int pad_h, int pad_w);
+size_t um_conv_stats_bytes(int batch, int parts, int channels);
 
 /* The encoder's 7x7 / stride-2 / pad-3 stem (unimatch/backbone.py:49; 3 input channels, no bias) on the same kernel, always
  * in the exact arithmetic.  image: fp32 NCHW [batch,3,h,w]; with `normalize` the reference's input normalisation
@@ -209,7 +212,7 @@ int um_stem_conv_fwd(const float* image, int normalize, const float* mean3, cons
 size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channels);
 int um_nhwc_instance_norm(const float* x, const float* shortcut, const void* shortcut_planes, void* planes_out, float* f32_out,
                           int batch, int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats,
-                          void* workspace, size_t workspace_bytes, int mode, void* stream);
+                          int conv_stats_parts, void* workspace, size_t workspace_bytes, int mode, void* stream);
 
 /* Channels-last element-wise helpers of the refinement block (SepConvGRU, unimatch/reg_refine.py:55-76); every result is
  * written as operand planes into columns [coff, coff + channels) of a buffer [NS = 2][plane_rows][ld]:

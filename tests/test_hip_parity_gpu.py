@@ -413,6 +413,9 @@ def _nhwc_planes(ops, x_nchw):
     (1, 96, 64, 24, 96, 3, 3, 1, 1, 1, True, False),         # patch kernel, six channel chunks, 3 x 3 tiles (an interior one)
     (1, 128, 128, 24, 32, 3, 3, 1, 1, 1, False, True),       # patch kernel NT = 4
     (2, 96, 96, 16, 32, 3, 3, 1, 1, 1, True, True),          # patch kernel NT = 3 (epilogue in two passes)
+    (2, 64, 64, 22, 60, 3, 3, 1, 1, 1, False, False),        # patch kernel, ragged right and bottom tiles
+    (1, 128, 128, 15, 90, 3, 3, 1, 1, 1, True, True),        # patch kernel NT = 4, ragged
+    (1, 96, 96, 30, 31, 3, 3, 1, 1, 1, True, False),         # patch kernel NT = 3, one ragged column of tiles
     (2, 128, 256, 8, 64, 3, 3, 1, 1, 1, True, True),         # patch kernel NT = 4, two output tiles
 ])
 def test_conv2d_nhwc_matches_fp64(ops, case):
@@ -570,6 +573,9 @@ def test_stem_conv_matches_fp64(ops, bhw, normalize):
                                             (64, (16, 64), 1),        # 2-D patch kernel: parts in tile order
                                             (128, (24, 32), 1),       # patch kernel NT = 4
                                             (96, (16, 64), 1),        # patch kernel NT = 3
+                                            (64, (22, 60), 1),        # patch kernel, ragged tiles: parts with 0 .. 128 pixels
+                                            (96, (30, 31), 1),
+                                            (128, (15, 90), 1),
                                             (64, (47, 63), 2)])       # KITTI-like odd map
 def test_conv_epilogue_statistics_feed_the_norm(ops, cout, hw, stride):
     """um_conv2d_fwd(stats_out) -> um_nhwc_instance_norm(conv_stats): the per-tile statistics written by the convolution's

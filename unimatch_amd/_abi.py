@@ -39,13 +39,14 @@ SIGNATURES = {
     'um_conv2d_gru_fwd': (_c_int, [_c_int, _c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                    _c_void_p, _c_int, _c_void_p, _c_int, _c_int, ctypes.c_long] + [_c_int] * 11 + [_c_void_p]),
     'um_conv_stats_bytes': (_c_size_t, [_c_int] * 3),
+    'um_conv_stats_parts': (_c_int, [_c_int] * 8),
     'um_stem_planes_bytes': (_c_size_t, [_c_int] * 3),
     'um_conv7_planes_bytes': (_c_size_t, [_c_int] * 4),
     'um_conv7_fwd': (_c_int, [_c_void_p, _c_int, _c_int] + [_c_void_p] * 6 + [_c_int, _c_int, _c_void_p, _c_int, _c_int, ctypes.c_long,
                               _c_void_p] + [_c_int] * 7 + [_c_void_p]),
     'um_stem_conv_fwd': (_c_int, [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
     'um_nhwc_norm_workspace_bytes': (_c_size_t, [_c_int] * 3),
-    'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 5 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_void_p,
+    'um_nhwc_instance_norm': (_c_int, [_c_void_p] * 5 + [_c_int] * 3 + [ctypes.c_float, _c_int, _c_int, _c_void_p, _c_int, _c_void_p,
                                        _c_size_t, _c_int, _c_void_p]),
     'um_nchw_to_nhwc': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_flow_warp': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),

@@ -73,8 +73,8 @@ struct IntC {
 
 template <typename T, int NS, int NT, int NT0, int NTP, int WSTRIDE>   // WSTRIDE: bytes of a wave's private staging block
 __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                                   int bt, int rloc0, int nvalid, int part0, int n0, int tid, int wave, int lane,
-                                                   int half) {
+                                                   int bt, int rloc0, int nvalid, int part0, bool dense_parts, int n0, int tid,
+                                                   int wave, int lane, int half) {
     const int P = a.Ho * a.Wo;                                    // pixels per image
     // The tile goes through the idle staging ring (every wave transposes its own 32 x 32NTP block; 16-byte chunk c of
     // row r at chunk c ^ (r & 7)) and leaves as full rows: direct stores from this layout hit 32 partial lines each.
@@ -167,7 +167,8 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         __syncthreads();
         // threads 0 .. 32 NTP - 1 of every group of four waves merge that group's 128 pixels
         const int grp = tid >> 8, gt = tid & 255;
-        if (gt < 32 * NTP && nb + gt < a.Cout && cnt[4 * grp] > 0.f) {       // a group's first wave has pixels if any has
+        // a group's first wave has pixels if any has; an empty group writes nothing unless the kernel numbers its parts densely
+        if (gt < 32 * NTP && nb + gt < a.Cout && (cnt[4 * grp] > 0.f || dense_parts)) {
             const float* w0 = reinterpret_cast<const float*>(scratch) + grp * 4 * (2 * 32 * NT) + 32 * NT0;
             float mean = w0[gt], m2 = w0[32 * NT + gt];
             float n = cnt[4 * grp];
@@ -183,9 +184,9 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                 }
             }
             float* pr = a.stats + ((long)(part0 + grp) * 3) * a.Cout + nb + gt;
-            pr[0] = mean;
-            pr[a.Cout] = 0.f;
-            pr[2 * a.Cout] = m2;
+            pr[0] = n > 0.f ? mean : 0.f;                                   // part = (mean, pixel count, sum of squared deviations)
+            pr[a.Cout] = n;
+            pr[2 * a.Cout] = n > 0.f ? m2 : 0.f;
         }
     }
     // ---- full-row stores: wave-uniform 64-bit bases, 32-bit lane offsets
@@ -246,14 +247,14 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
 // NTE = n-tiles per epilogue pass (NT: the whole tile at once).
 template <typename T, int NS, int NT, int NTE = NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], unsigned char* lds, unsigned char* scratch,
-                                              int bt, int rloc0, int nvalid, int part0, int n0, int tid, int wave, int lane,
-                                              int half) {
+                                              int bt, int rloc0, int nvalid, int part0, bool dense_parts, int n0, int tid, int wave,
+                                              int lane, int half) {
     constexpr int NP = NTE < NT ? NTE : NT;
     constexpr int WSTRIDE = 32 * (32 * NP * 4);
-    conv_epilogue_pass<T, NS, NT, 0, NP, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, n0, tid, wave, lane, half);
+    conv_epilogue_pass<T, NS, NT, 0, NP, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, dense_parts, n0, tid, wave, lane, half);
     if constexpr (NTE < NT)          // the wave's staging block is private and DS operations of a wave execute in order
-        conv_epilogue_pass<T, NS, NT, NTE, NT - NTE, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, n0, tid, wave, lane,
-                                                              half);
+        conv_epilogue_pass<T, NS, NT, NTE, NT - NTE, WSTRIDE>(a, acc, lds, scratch, bt, rloc0, nvalid, part0, dense_parts, n0, tid, wave,
+                                                              lane, half);
 }
 
 template <typename T, int NS, int NT>
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 
     {
         const int rloc0 = pl0 + 32 * wave;
-        conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, rloc0, min(32, max(0, P - rloc0)), bt * ((P + 127) / 128) + pl0 / 128, n0, tid,
-                                 wave, lane, half);
+        conv_epilogue<T, NS, NT>(a, acc, lds, lds + RING, bt, rloc0, min(32, max(0, P - rloc0)), bt * ((P + 127) / 128) + pl0 / 128, false,
+                                 n0, tid, wave, lane, half);
     }
 }
 
@@ -619,12 +620,12 @@ __global__ __launch_bounds__(512, (NSLOT == 2 && NT < 4 ? 2 : 1)) void conv_rows
     {
         const int rloc0 = pl0 + 32 * wave;
         conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + RING, bt, rloc0, min(32, max(0, P - rloc0)), bt * ((P + 127) / 128) + pl0 / 128,
-                                         n0, tid, wave, lane, half);
+                                         false, n0, tid, wave, lane, half);
     }
 }
 
 
-// ---- 2-D patch variant: 3x3 / stride 1 / pad 1 on maps whose height is a multiple of 8 and width a multiple of 32 -------------
+// ---- 2-D patch variant: 3x3 / stride 1 / pad 1 ------------------------------------------------------------------------------
 // The row-window kernel still stages a tile's activations once per kernel ROW: three windows, image-row-length apart, that a
 // 4 MB L2 shared by 64 resident tiles does not keep (1.3 GB fetched per launch for 0.4 GB of input at 256 x 384 x 16).  Here
 // the tile is 8 rows x 32 columns and its (8 + 2) x (32 + 2) halo patch is staged ONCE per 16-channel chunk and serves all
@@ -632,7 +633,9 @@ __global__ __launch_bounds__(512, (NSLOT == 2 && NT < 4 ? 2 : 1)) void conv_rows
 // 32-byte rows at any offset, conflict-free with the chunk c ^ ((r >> 3) & 1) layout.  2.5x fewer activation bytes through
 // L2 / LDS-DMA, no tap masks, no per-row index arithmetic (out-of-image patch pixels point at the zero row once).  Stages are
 // (chunk, kernel row): the patch is double-buffered per chunk, the three weight tiles of a kernel row per stage; <= 80 KB at
-// NT = 2 so two workgroups share a CU.  With H % 8 == 0 and W % 32 == 0 every statistics part is a full 128 pixels.
+// NT = 2 / 3 so two workgroups share a CU.  Maps that are not whole tiles have ragged right / bottom tiles (waves with fewer
+// than 32, or no, valid pixels); the dispatcher uses this kernel when at least 3/4 of the tiled area is image.  A statistics
+// part is a group of four tile rows, numbered densely (2 per tile), with its pixel count.
 template <int NS, int NT>
 struct ConvPatchLds {
     static constexpr int NTE = NT < 2 ? NT : 2;
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_patch_kernel(ConvA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, fr = lane & 31;
-    const int P = a.Ho * a.Wo, twn = a.Wo >> 5, tpi = twn * (a.Ho >> 3);        // tiles per row / per image
+    const int twn = (a.Wo + 31) >> 5, tpi = twn * ((a.Ho + 7) >> 3);             // tiles per row / per image
     const int ny = (a.Cout + 32 * NT - 1) / (32 * NT);           // 1-D XCD-aware grid, see conv_kernel
     const int wg = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tile = wg / ny;
@@ -765,8 +768,9 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_patch_kernel(ConvA
             __syncthreads();
         }
     }
-    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + L::EPI, bt, (y0 + wave) * a.Wo + x0, 32, bt * (P >> 7) + 2 * tt, n0, tid, wave,
-                                     lane, half);
+    const int nvalid = y0 + wave < a.Ho ? min(32, a.Wo - x0) : 0;               // this wave's pixels inside the image
+    conv_epilogue<T, NS, NT, L::NTE>(a, acc, lds, lds + L::EPI, bt, (y0 + wave) * a.Wo + x0, nvalid, (bt * tpi + tt) * 2, true, n0, tid,
+                                     wave, lane, half);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -818,7 +822,7 @@ static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stre
 template <int NT>
 static hipError_t launch_conv_patch(const ConvArgs& a, int mode, hipStream_t stream) {
     static bool configured[2] = {false, false};    // opt in to > 64 KB of LDS once per instantiation
-    dim3 grid(a.B * (a.Ho / 8) * (a.Wo / 32) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
+    dim3 grid(a.B * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(512);
     constexpr int LDS2 = ConvPatchLds<2, NT>::TOTAL, LDS1 = ConvPatchLds<1, NT>::TOTAL;
     static_assert(LDS2 <= 160 * 1024 && LDS1 <= 160 * 1024, "ring beyond the CU's LDS");
     ScopedKernelTimer timer(UM_K_CONV, stream);
@@ -840,6 +844,36 @@ static hipError_t launch_conv_patch(const ConvArgs& a, int mode, hipStream_t str
         hipLaunchKernelGGL((conv_patch_kernel<Bf16, 1, NT>), grid, block, LDS1, stream, a);
     }
     return hipGetLastError();
+}
+
+// ---- which kernel serves a geometry (one place: um_conv_stats_parts() must agree with the launch)
+enum ConvKind { CONV_GENERIC = 0, CONV_ROWS = 1, CONV_PATCH = 2 };
+
+static ConvKind conv_pick(int hi, int wi, int ho, int wo, int cout, int kh, int kw, int stride, int pad_h, int pad_w, int* nt_out) {
+    // widest output tile that does not waste more than a third of its columns
+    const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
+    *nt_out = nt;
+    // A/B switches (tools/ab_bench.py), read once: UM_CONV_NO_ROWS = generic kernel only; UM_CONV_PATCH = the tile widths
+    // (digits of NT) the 2-D patch kernel may serve
+    static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;
+    static const char* patch_env = getenv("UM_CONV_PATCH");
+    static const char* patch_nts = patch_env ? patch_env : "234";
+    // same-size stride-1 rows of 3 taps (any tile width) or 5 taps (128-wide tiles: the GRU's 1x5 gates): row-window kernel
+    const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;
+    const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
+    // 3x3: the 2-D patch kernel when at least 3/4 of the 8 x 32 tiles' area is image
+    const long tiled = (long)((ho + 7) / 8 * 8) * ((wo + 31) / 32 * 32);
+    if (rows3 && kh == 3 && pad_h == 1 && 4L * ho * wo >= 3 * tiled && strchr(patch_nts, '0' + nt) != nullptr) return CONV_PATCH;
+    return rows3 || rows5 ? CONV_ROWS : CONV_GENERIC;
+}
+
+extern "C" int um_conv_stats_parts(int hi, int wi, int cout, int kh, int kw, int stride, int pad_h, int pad_w) {
+    if (hi <= 0 || wi <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0) return -1;
+    const int ho = (hi + 2 * pad_h - kh) / stride + 1, wo = (wi + 2 * pad_w - kw) / stride + 1;
+    if (ho <= 0 || wo <= 0) return -1;
+    int nt;
+    if (conv_pick(hi, wi, ho, wo, cout, kh, kw, stride, pad_h, pad_w, &nt) == CONV_PATCH) return 2 * ((ho + 7) / 8) * ((wo + 31) / 32);
+    return (int)(((long)ho * wo + 127) / 128);
 }
 
 static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
@@ -917,26 +951,13 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     a.out_scale = ldexpf(1.f, -wshift);
     a.xcd = conv_xcd_enabled();
     hipError_t e;
-    // widest output tile that does not waste more than a third of its columns
-    const int nt = (cout % 128 == 0 || cout > 192) ? 4 : (cout % 96 == 0) ? 3 : (cout <= 64 || cout % 64 == 0) ? 2 : 4;
-    // same-size stride-1 rows of 3 taps (any tile width) or 5 taps (128-wide tiles: the GRU's 1x5 gates): row-window kernel
-    static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;       // A/B switch (tools/ab_bench.py), read once
-    const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;
-    const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
-    // 3x3 on maps made of whole 8 x 32 tiles: the 2-D patch kernel (UM_CONV_PATCH = the tile widths it may serve, A/B switch)
-    static const char* patch_env = getenv("UM_CONV_PATCH");
-    static const char* patch_nts = patch_env ? patch_env : "234";
-    const bool patch = rows3 && kh == 3 && pad_h == 1 && hi % 8 == 0 && wi % 32 == 0 && strchr(patch_nts, '0' + nt) != nullptr;
-    if (patch && nt == 2) e = launch_conv_patch<2>(a, mode, (hipStream_t)stream_);
-    else if (patch && nt == 3) e = launch_conv_patch<3>(a, mode, (hipStream_t)stream_);
-    else if (patch && nt == 4) e = launch_conv_patch<4>(a, mode, (hipStream_t)stream_);
-    else if (rows3 && nt == 2) e = launch_conv_rows<2, 3, 2>(a, mode, (hipStream_t)stream_);
-    else if (rows3 && nt == 3) e = launch_conv_rows<3, 3, 2>(a, mode, (hipStream_t)stream_);
-    else if (rows3 && nt == 4) e = launch_conv_rows<4, 3, 2>(a, mode, (hipStream_t)stream_);
-    else if (rows5) e = launch_conv_rows<4, 5, 2>(a, mode, (hipStream_t)stream_);
-    else if (nt == 4) e = launch_conv<4>(a, mode, (hipStream_t)stream_);
-    else if (nt == 3) e = launch_conv<3>(a, mode, (hipStream_t)stream_);
-    else e = launch_conv<2>(a, mode, (hipStream_t)stream_);
+    int nt;
+    const ConvKind kind = conv_pick(hi, wi, ho, wo, cout, kh, kw, stride, pad_h, pad_w, &nt);
+    hipStream_t st = (hipStream_t)stream_;
+    if (kind == CONV_PATCH) e = nt == 2 ? launch_conv_patch<2>(a, mode, st) : nt == 3 ? launch_conv_patch<3>(a, mode, st) : launch_conv_patch<4>(a, mode, st);
+    else if (kind == CONV_ROWS && kw == 5) e = launch_conv_rows<4, 5, 2>(a, mode, st);
+    else if (kind == CONV_ROWS) e = nt == 2 ? launch_conv_rows<2, 3, 2>(a, mode, st) : nt == 3 ? launch_conv_rows<3, 3, 2>(a, mode, st) : launch_conv_rows<4, 3, 2>(a, mode, st);
+    else e = nt == 2 ? launch_conv<2>(a, mode, st) : nt == 3 ? launch_conv<3>(a, mode, st) : launch_conv<4>(a, mode, st);
     if (e != hipSuccess) {
         um_set_error("um_conv2d: launch failed: %s", hipGetErrorString(e));
         return (int)e;

@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void nhwc_stats_kernel(const float* x, float* 
 }
 
 // ---- pass 2: merge the chunks (fp64, Chan et al.) -> stats[b][0][c] = mean, stats[b][1][c] = rstd ---------------------
-// partial[b][part][3][C] = (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short):
-// written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS) or by conv_kernel's epilogue (rpp = 128, k = tile mean).
+// partial[b][part][3][C], either (shift k, sum(x - k), sum((x - k)^2)) over `rpp` pixels per part (the last one may be short),
+// written by nhwc_stats_kernel (rpp = NHWC_CHUNK_ROWS), or -- rpp == 0 -- (mean, pixel count, sum of squared deviations) as
+// written by the convolutions' epilogues (parts of <= 128 pixels in the order of the kernel's tiles; empty parts have count 0).
 // grid (C / 8, B), block 256 = 8 channels x 32 lanes.  All in fp64 and in a fixed order (deterministic): the mean from the
 // sums, then sum(M2_i + n_i (mean_i - mean)^2) -- the parallel-variance formula with the global mean known, so there is no
 // division inside the loops.  The parts were written by other XCDs (a microsecond away): up to 1024 parts per image every
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
     __shared__ double bc[8];
     const int b = blockIdx.y;
     const int ch = threadIdx.x & 7, c = blockIdx.x * 8 + ch, ln = threadIdx.x >> 3;
-    const int tail = P - (nparts - 1) * rpp;                      // pixels of the last part
-    const double inv_full = 1.0 / (double)rpp, inv_tail = 1.0 / (double)tail;
+    const bool counted = rpp == 0;                                // parts carry their pixel count
+    const int tail = counted ? 1 : P - (nparts - 1) * rpp;        // pixels of the last part
+    const double inv_full = counted ? 0.0 : 1.0 / (double)rpp, inv_tail = 1.0 / (double)tail;
     const float* base = partial + ((long)b * nparts * 3) * C + c;
     constexpr int NB = 32;                                        // parts per lane held in registers
     const bool in_regs = nparts <= 32 * NB;
@@ -88,13 +90,16 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int pt = ln + 32 * j;
-            if (pt < nparts) sx += (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)rk[j] + (double)r1[j];
+            if (pt < nparts)
+                sx += counted ? (double)r1[j] * (double)rk[j]
+                              : (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)rk[j] + (double)r1[j];
         }
     } else {
 #pragma unroll 8
         for (int pt = ln; pt < nparts; pt += 32) {
             const float* pr = base + (long)pt * 3 * C;
-            sx += (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)pr[0] + (double)pr[C];   // sum of x = n k + sum(x - k)
+            sx += counted ? (double)pr[C] * (double)pr[0]
+                          : (pt == nparts - 1 ? (double)tail : (double)rpp) * (double)pr[0] + (double)pr[C];   // sum of x = n k + sum(x - k)
         }
     }
     red[threadIdx.x] = sx;
@@ -108,6 +113,11 @@ __global__ __launch_bounds__(256) void nhwc_stats_finalize_kernel(const float* p
     const double mean = bc[ch];
     double m2 = 0.0;
     auto add_part = [&](int pt, double k, double s1, double s2) {
+        if (counted) {                                            // (mean, n, M2)
+            const double d = k - mean;
+            m2 += s2 + s1 * d * d;
+            return;
+        }
         const bool last = pt == nparts - 1;
         const double n = last ? (double)tail : (double)rpp, inv = last ? inv_tail : inv_full;
         const double d = k + s1 * inv - mean;
@@ -321,15 +331,15 @@ extern "C" size_t um_nhwc_norm_workspace_bytes(int batch, int pixels, int channe
     return (size_t)((long)batch * nchunk * 3 * channels + (long)batch * 2 * channels) * sizeof(float);
 }
 
-extern "C" size_t um_conv_stats_bytes(int batch, int pixels, int channels) {
-    if (batch <= 0 || pixels <= 0 || channels <= 0) return 0;
-    return (size_t)((long)batch * ((pixels + 127) / 128) * 3 * channels) * sizeof(float);
+extern "C" size_t um_conv_stats_bytes(int batch, int parts, int channels) {
+    if (batch <= 0 || parts <= 0 || channels <= 0) return 0;
+    return (size_t)((long)batch * parts * 3 * channels) * sizeof(float);
 }
 
 static bool nhwc_channels_ok(int c) { return c > 0 && c % 8 == 0 && c <= 256; }
 
 extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, const void* shortcut_planes, void* planes_out, float* f32_out, int batch,
-                                     int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats,
+                                     int pixels, int channels, float eps, int normalize, int relu, const float* conv_stats, int conv_stats_parts,
                                      void* workspace, size_t workspace_bytes, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || (!planes_out && !f32_out) || batch <= 0 || pixels <= 0 || !nhwc_channels_ok(channels) || (mode != 0 && mode != 1)) {
@@ -348,9 +358,13 @@ extern "C" int um_nhwc_instance_norm(const float* x, const float* shortcut, cons
             return -3;
         }
         stats = partial + (long)batch * nchunk * 3 * channels;
-        if (conv_stats) {                                          // per-128-pixel tile statistics from um_conv2d_fwd
+        if (conv_stats) {                                          // per-tile statistics from the producing convolution
+            if (conv_stats_parts <= 0) {
+                um_set_error("um_nhwc_instance_norm: conv_stats needs conv_stats_parts = um_conv_stats_parts() of the convolution");
+                return -1;
+            }
             hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, conv_stats, stats, pixels, channels,
-                               (pixels + 127) / 128, 128, eps);
+                               conv_stats_parts, 0, eps);
         } else {
             hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, partial, pixels, channels, nchunk);
             hipLaunchKernelGGL(nhwc_stats_finalize_kernel, dim3(channels / 8, batch), dim3(256), 0, stream, partial, stats, pixels, channels,

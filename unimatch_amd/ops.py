@@ -313,10 +313,11 @@ class HipOps:
         ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
         out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=planes.device)
         self.last_conv_stats = None
-        if stats:
-            self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
-                                               device=planes.device)
-        st = self.last_conv_stats
+        if stats:                                    # (per-part statistics, parts per image): hand both to nhwc_norm(conv_stats=)
+            parts = self.lib.um_conv_stats_parts(h, w, cout, kh, kw, stride, ph, pw)
+            self.last_conv_stats = (torch.empty(self.lib.um_conv_stats_bytes(b, parts, cout) // 4, dtype=torch.float32,
+                                                device=planes.device), parts)
+        st = self.last_conv_stats[0] if self.last_conv_stats is not None else None
         meta = {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin}
         code = self._launch('conv', lambda: self.lib.um_conv2d_fwd(
             _ptr(planes), _ptr(wp), _ptr(bias) if bias is not None else None, _ptr(out), _ptr(st) if st is not None else None,
@@ -468,9 +469,10 @@ class HipOps:
         out = torch.empty((b * ho * wo, cout), dtype=torch.float32, device=image.device)
         self.last_conv_stats = None
         if stats:
-            self.last_conv_stats = torch.empty(self.lib.um_conv_stats_bytes(b, ho * wo, cout) // 4, dtype=torch.float32,
-                                               device=image.device)
-        st = self.last_conv_stats
+            parts = self.lib.um_conv_stats_parts(h, w, cout, 7, 7, 2, 3, 3)
+            self.last_conv_stats = (torch.empty(self.lib.um_conv_stats_bytes(b, parts, cout) // 4, dtype=torch.float32,
+                                                device=image.device), parts)
+        st = self.last_conv_stats[0] if self.last_conv_stats is not None else None
         if norm_mean_std is not None:
             mean = (ctypes.c_float * 3)(*[float(v) for v in norm_mean_std[0]])
             std = (ctypes.c_float * 3)(*[float(v) for v in norm_mean_std[1]])
@@ -486,7 +488,8 @@ class HipOps:
     def nhwc_norm(self, x, b, pixels, normalize=True, relu=True, shortcut=None, want_planes=True, want_f32=False, eps=1e-5,
                   conv_stats=None, shortcut_planes=None):
         """InstanceNorm (+ ReLU, + shortcut + ReLU) of fp32 NHWC ``x [b*pixels, c]`` -> ``(planes | None, f32 | None)``.
-        The shortcut is fp32 ``[b*pixels, c]`` or (``shortcut_planes``) operand planes of the same shape."""
+        The shortcut is fp32 ``[b*pixels, c]`` or (``shortcut_planes``) operand planes of the same shape; ``conv_stats`` is the
+        ``(statistics, parts per image)`` pair the producing convolution left in ``last_conv_stats``."""
         self._check_rows('x', x, x.shape[1])
         c = x.shape[1]
         if x.shape[0] != b * pixels:
@@ -504,7 +507,8 @@ class HipOps:
             _ptr(x), _ptr(shortcut) if shortcut is not None else None,
             _ptr(shortcut_planes) if shortcut_planes is not None else None, _ptr(planes) if planes is not None else None,
             _ptr(f32) if f32 is not None else None, b, pixels, c, float(eps), int(bool(normalize)), int(bool(relu)),
-            _ptr(conv_stats) if conv_stats is not None else None, _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
+            _ptr(conv_stats[0]) if conv_stats is not None else None, conv_stats[1] if conv_stats is not None else 0,
+            _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, self.CONV_MODE, _stream()))
         _abi.check(code, 'um_nhwc_instance_norm')
         return planes, f32
 
