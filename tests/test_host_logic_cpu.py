@@ -169,6 +169,29 @@ def test_abi_argument_errors_without_gpu():
     assert rc == -4
 
 
+def test_conv_statistics_bookkeeping_without_gpu():
+    """um_conv_stats_parts() (host-side dispatch, no launch): the number of statistics parts per image a convolution's
+    epilogue writes -- 128-pixel parts for the generic / row-window kernels, two parts per 8 x 32 tile where the 2-D patch
+    kernel serves (3x3, stride 1, pad 1, at least 3/4 of the tiling inside the image); and the argument checks of the
+    entry points that consume them."""
+    lib = _abi.load()
+    parts = lib.um_conv_stats_parts
+    assert parts(256, 384, 64, 3, 3, 1, 1, 1) == 2 * 32 * 12                 # patch kernel: whole tiles
+    assert parts(22, 60, 64, 3, 3, 1, 1, 1) == 2 * 3 * 2                     # patch kernel: ragged tiles
+    assert parts(40, 7, 64, 3, 3, 1, 1, 1) == (40 * 7 + 127) // 128          # 7 of 32 columns: row-window kernel instead
+    assert parts(8, 12, 128, 3, 3, 1, 1, 1) == 1                             # < 256 pixels: generic kernel
+    assert parts(21, 30, 96, 3, 3, 2, 1, 1) == (11 * 15 + 127) // 128        # stride 2
+    assert parts(512, 768, 64, 7, 7, 2, 3, 3) == 256 * 384 // 128            # the stem
+    assert parts(16, 24, 128, 1, 5, 1, 0, 2) == 3                            # GRU 1x5: row-window kernel
+    assert parts(0, 24, 128, 3, 3, 1, 1, 1) == -1 and parts(4, 4, 64, 7, 7, 1, 0, 0) == -1
+    assert lib.um_conv_stats_bytes(3, 24, 64) == 3 * 24 * 3 * 64 * 4 and lib.um_conv_stats_bytes(3, 0, 64) == 0
+    fake = ctypes.c_void_p(4096)
+    rc = lib.um_conv2d_fwd(fake, fake, ctypes.c_void_p(4100), fake, None, 1, 16, 32, 64, 64, 3, 3, 1, 1, 1, 0, 10, 0, None)
+    assert rc == -1 and b'aligned' in lib.um_last_error_string()             # bias must be 16-byte aligned
+    rc = lib.um_conv2d_fwd(fake, fake, None, fake, None, 1, 16, 32, 48, 64, 3, 3, 1, 1, 1, 0, 10, 0, None)
+    assert rc == -1                                                          # cin not a multiple of 32
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the GPU-less failure mode')
 def test_hot_path_fails_loudly_without_gpu():
     model, sd, i0, i1, kw, ck = build('gmflow_s1')
