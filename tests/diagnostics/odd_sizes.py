@@ -20,8 +20,16 @@ def diff(a, b):
     return d.pow(2).sum(1).sqrt().mean().item() if d.dim() == 4 else d.abs().mean().item()
 
 
-for name, b, hh, ww in (('gmflow_s1', 1, 448, 1024), ('gmflow_s1', 2, 384, 1248), ('gmflow_s2_rr6', 1, 448, 1024),
-                        ('gmstereo_s2_rr3', 1, 384, 1248), ('gmflow_s2_rr6', 1, 256, 384)):
+QUICK = '--quick' in sys.argv           # two ragged cases, default vs MIOpen convolutions only
+CASES = (('gmflow_s1', 1, 448, 1024), ('gmflow_s1', 2, 384, 1248), ('gmflow_s2_rr6', 1, 448, 1024),
+         ('gmstereo_s2_rr3', 1, 384, 1248), ('gmflow_s2_rr6', 1, 256, 384))
+VARIANTS = (('default', {}), ('miopen convs', {'fused_conv': False}), ('two-launch ffn', {'fused_ffn': False}),
+            ('separate merge', {'fused_merge': False}))
+if QUICK:
+    CASES, VARIANTS = (CASES[1], CASES[3]), VARIANTS[:2]
+if '--case' in sys.argv:                # one case, every variant
+    CASES = (CASES[int(sys.argv[sys.argv.index('--case') + 1])],)
+for name, b, hh, ww in CASES:
     ck, fk = CONFIGS[name]
     model = UniMatch(**ck).eval()
     model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
@@ -29,8 +37,7 @@ for name, b, hh, ww in (('gmflow_s1', 1, 448, 1024), ('gmflow_s1', 2, 384, 1248)
     i0, i1 = synth_images(b, hh, ww, seed=5, kind='shift', normalized=(fk['task'] != 'flow'))
     i0, i1 = i0.cuda(), i1.cuda()
     outs = {}
-    for tag, attrs in (('default', {}), ('miopen convs', {'fused_conv': False}), ('two-launch ffn', {'fused_ffn': False}),
-                       ('separate merge', {'fused_merge': False})):
+    for tag, attrs in VARIANTS:
         ops = HipOps('exact')
         for k, v in attrs.items():
             setattr(ops, k, v)
