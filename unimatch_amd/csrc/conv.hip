@@ -15,7 +15,14 @@
 // workgroup moves a [128 pixels x 32 channels] activation tile and a [32 NT outputs x 32] weight tile into a 2-slot
 // LDS ring by LDS-DMA -- the only per-tap work is two row indices per lane.
 // Decomposition: workgroup = 4 waves = 128 output pixels x 32 NT output channels (NT = 2, 3, 4), wave = 32 pixels,
-// computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC (+ bias, optional ReLU).
+// computed transposed (D^T = W . A^T) so that lane = pixel.  Output: fp32 NHWC and / or the next convolution's operand
+// planes (+ bias, activation, SepConvGRU gates, InstanceNorm statistics), see conv_epilogue.
+//
+// Three kernels share the operand format and the epilogue; conv_pick() chooses:
+//   conv_kernel        any geometry (strides, 1x1, 5x1, 7x7 via um_conv7_fwd): one staged tile per tap and 32-channel chunk
+//   conv_rows_kernel   same-size stride-1 rows of 3 / 5 taps: one 256-pixel window per kernel row serves its KW taps
+//   conv_patch_kernel  3x3 / stride 1 / pad 1: an 8 x 32 pixel tile whose halo patch is staged once per 16-channel chunk for
+//                      all nine taps (the default for every 3x3 layer of the encoder and the refinement block)
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
