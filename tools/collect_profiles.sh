@@ -1,0 +1,28 @@
+#!/bin/bash
+# Evidence for profiles/ in ONE gpurun call (run from the repo root on the GPU box; ~3 GPU-minutes):
+#   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r02'
+# writes gpurun_out/<tag>_*: the bench.py line, the steady-state per-kernel breakdown of a traced bench.py, a FETCH_SIZE pass,
+# all five BASELINE configs, and the config-4 kernel statistics.  Copy what should be judged into profiles/.
+# Pitfalls this script encodes: rocprofv3 needs TMPDIR=/tmp and an explicit --output-format csv (the default is a database);
+# its stdin must not be the terminal; --pmc goes with --kernel-trace only; the raw kernel trace is large -- reduce it on the box.
+set -u
+TAG=${1:-rNN}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$R"
+timeout 240 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -o t -- \
+    python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_trace.log" 2>&1 < /dev/null)
+TRACE=$(find "$OUT/${TAG}_trace" -name '*kernel_trace.csv' | head -1)
+if [ -n "$TRACE" ]; then python tools/steady_state.py "$TRACE" 10 > "$OUT/${TAG}_steady_state.txt"; rm -f "$TRACE"; fi
+(cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/${TAG}_pmc -o p -- \
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_pmc.log" 2>&1 < /dev/null)
+PMC=$(find /tmp/${TAG}_pmc -name '*counter_collection.csv' | head -1)
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply window_attn gsv_kernel ffn_kernel linear_kernel > "$OUT/${TAG}_pmc_fetch.json"; fi
+timeout 150 python tools/bench_configs.py --steps 10 2>&1 | grep cfg > "$OUT/${TAG}_all_configs.txt"
+(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_cfg4" -o p -- \
+    python "$R/tools/profile_config.py" gmflow_s2_rr6 4 512 768 > "$OUT/${TAG}_cfg4.log" 2>&1 < /dev/null)
+rm -f "$OUT/${TAG}_cfg4"/*kernel_trace.csv
+ls -la "$OUT" | tail -12
