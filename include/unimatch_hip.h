@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UM_VERSION 100
+#define UM_VERSION 200
 
 #define UM_MODE_EXACT 0
 #define UM_MODE_FAST 1
@@ -42,6 +42,7 @@ extern "C" {
 #define UM_ERR_BAD_GEOMETRY (-2) /* window does not tile the map, shift >= window ...             */
 #define UM_ERR_WORKSPACE (-3)    /* workspace missing or too small                                  */
 #define UM_ERR_UNSUPPORTED (-4)  /* valid in the reference but not implemented by this library      */
+#define UM_ERR_COLLECTIVE (-5)   /* RCCL reported an error / the communicator bootstrap failed       */
 
 int um_version(void);
 const char* um_last_error_string(void);
@@ -316,6 +317,32 @@ int um_flow_warp(const float* feature_tokens, const float* flow, float* out_toke
  * ------------------------------------------------------------------------------------------- */
 int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long planes, int hw, float eps,
                          int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: collecting the predictions (SURVEY.md 8b "allgather_preds", 8e).
+ *
+ * The path shards by sample (one process per GPU, contiguous batch split, weights replicated) and needs no collective
+ * to COMPUTE; the one exchange is an all-gather of the final prediction over RCCL / xGMI.  The reference has no
+ * inference-time collective; its process-group bring-up (utils/dist_utils.py:12-30, launcher
+ * scripts/gmflow_scale1_train.sh:12) is what um_comm_* replaces, torch-free:
+ *   um_comm_unique_id   rank 0 obtains the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *                       (torch.distributed store, MPI, a file);
+ *   um_comm_init_rank   every rank: ncclCommInitRank on the calling thread's current HIP device;
+ *   um_comm_init_file   both steps through a file on a filesystem all ranks see: rank 0 publishes `path` atomically, the
+ *                       others poll for it up to timeout_seconds (< 0: forever).  The caller chooses a job-unique path.
+ *   um_allgather_preds  ncclAllGather(send, recv, count_per_rank floats) enqueued on `stream` (the caller's compute or side
+ *                       stream; no host synchronisation).  recv: [world][count_per_rank], rank major.
+ *   um_comm_world       number of ranks of the communicator (ncclCommCount);  um_comm_destroy releases it.
+ * RCCL is bound at first use by soname (librccl.so.1); without it these return UM_ERR_UNSUPPORTED.  The communicator is
+ * the ONLY state the library ever holds on behalf of a caller, and it is an explicit handle.
+ * ------------------------------------------------------------------------------------------- */
+#define UM_COMM_ID_BYTES 128
+int um_comm_unique_id(void* id_out /* UM_COMM_ID_BYTES, host */);
+int um_comm_init_rank(void** comm_out, const void* id /* UM_COMM_ID_BYTES, host */, int rank, int world);
+int um_comm_init_file(void** comm_out, const char* path, int rank, int world, int timeout_seconds);
+int um_comm_world(void* comm);
+int um_comm_destroy(void* comm);
+int um_allgather_preds(void* comm, const float* send, float* recv, size_t count_per_rank, void* stream);
 
 #ifdef __cplusplus
 }

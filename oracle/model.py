@@ -215,6 +215,8 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
                 flow = flow + delta
             if task == 'stereo':
                 flow = flow.clamp(min=0)
+            if taps is not None:
+                taps[f'flow_it{it}'] = flow
             if it == num_reg_refine - 1:
                 if task == 'depth':
                     pad = torch.cat([flow, torch.zeros_like(flow)], 1)

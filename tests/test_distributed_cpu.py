@@ -2,6 +2,9 @@
 shards and bidirectional layouts, and the wrapped model against the single-process full-batch result."""
 import os
 import socket
+import subprocess
+import sys
+import textwrap
 
 import pytest
 import torch
@@ -79,3 +82,39 @@ def test_world_size_two_gloo():
     assert sorted(r[0] for r in results) == [0, 1]
     for r in results:
         assert all(r[1:]), r
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_launcher_starts_every_rank(tmp_path):
+    """``launch_ranks`` -- what ``python bench.py --gpus N`` uses when no launcher started it -- runs N ranks under
+    torch.distributed.run with the rendezvous on 127.0.0.1 (driven here on CPU with a gloo all-reduce)."""
+    from unimatch_amd.dist import launch_ranks
+    script = tmp_path / 'ranks.py'
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, torch, torch.distributed as dist
+        dist.init_process_group('gloo')
+        t = torch.tensor([float(dist.get_rank() + 1)])
+        dist.all_reduce(t)
+        open(os.path.join(r'{tmp_path}', 'rank%d.txt' % dist.get_rank()), 'w').write('%d %d %s' % (dist.get_world_size(), int(t.item()), sys.argv[1]))
+        dist.destroy_process_group()
+    """))
+    assert launch_ranks(str(script), ['hello'], 2, need_gpus=False) == 0
+    for r in range(2):
+        assert (tmp_path / f'rank{r}.txt').read_text() == '2 3 hello'
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason='needs a node with fewer than 2 GPUs')
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` on a node with fewer than two GPUs must fail loudly, not print an n_gpus=1 line; and a
+    launcher whose WORLD_SIZE differs from --gpus is an error as well."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert out.returncode != 0 and '2 GPUs requested' in (out.stderr + out.stdout)
+    assert '"n_gpus"' not in out.stdout
+    env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert out.returncode != 0 and 'WORLD_SIZE=2' in (out.stderr + out.stdout)

@@ -147,7 +147,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_abi.SIGNATURES) == names                     # the ctypes table mirrors the header
-    assert _abi.load().um_version() == 100
+    assert _abi.load().um_version() == 200
 
 
 def test_abi_argument_errors_without_gpu():
@@ -167,6 +167,22 @@ def test_abi_argument_errors_without_gpu():
     assert rc == -3 and b'workspace' in lib.um_last_error_string()
     rc = lib.um_local_corr_softmax(fake, fake, fake, 1, 8, 12, 128, 40, 0, None)
     assert rc == -4
+
+
+def test_collective_entry_points_argument_errors_without_gpu():
+    """um_comm_* / um_allgather_preds: exported, and their argument checks run before RCCL is touched."""
+    lib = _abi.load()
+    comm = ctypes.c_void_p()
+    uid = (ctypes.c_ubyte * _abi.COMM_ID_BYTES)()
+    assert lib.um_comm_unique_id(None) == -1
+    assert lib.um_comm_init_rank(ctypes.byref(comm), uid, 2, 2) == -1 and b'outside' in lib.um_last_error_string()
+    assert lib.um_comm_init_rank(None, uid, 0, 1) == -1
+    assert lib.um_comm_init_file(ctypes.byref(comm), b'', 0, 1, 1) == -1
+    assert lib.um_comm_init_file(ctypes.byref(comm), b'/tmp/x', 3, 2, 1) == -1
+    fake = ctypes.c_void_p(4096)
+    assert lib.um_allgather_preds(None, fake, fake, 16, None) == -1 and b'null communicator' in lib.um_last_error_string()
+    assert lib.um_allgather_preds(fake, fake, fake, 0, None) == -1
+    assert lib.um_comm_destroy(None) == 0
 
 
 def test_conv_statistics_bookkeeping_without_gpu():

@@ -38,7 +38,7 @@ def main():
         for label, extra in variants:
             env = dict(os.environ)
             env.update(extra)
-            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--steps', steps],
+            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--no-fast', '--steps', steps],
                                  capture_output=True, text=True, env=env, cwd=ROOT)
             try:
                 d = json.loads(out.stdout.strip().splitlines()[-1])

@@ -1,0 +1,55 @@
+"""Turn per-kernel rocprofv3 PMC summaries (tools/pmc_summary.py output of a FETCH_SIZE pass and of a WRITE_SIZE pass over
+bench.py) into profiles/pmc_current.json: corrected HBM bytes per launch of the two roofline kernels, stamped with the sha256 of
+the kernel sources and the git commit they were measured at.  bench.py quotes `roofline.traffic` from that file and nulls it
+when the stamp no longer matches the tree.  Run in the build container after the GPU call:
+
+    python tools/pmc_roofline.py gpurun_out/r02_pmc_fetch.json gpurun_out/r02_pmc_write.json [--from-r01]
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte requests as 64 bytes -> read bytes =
+2 x FETCH_SIZE(KiB) x 1024 for the wide coalesced rows these kernels stream; WRITE_SIZE(KiB) x 1024 as is.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import PMC_FILE, source_stamp  # noqa: E402
+
+KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv_kernel': ['global_match.hip', 'common.h']}
+
+
+def main():
+    git = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+    dirty = bool(subprocess.run(['git', 'status', '--porcelain', 'unimatch_amd/csrc'], capture_output=True, text=True,
+                                cwd=ROOT).stdout.strip())
+    out = {'git': git + ('+dirty' if dirty else ''),
+           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) over `python bench.py '
+                   '--steps 3 --warmup 2 --no-cpu-baseline`; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction), write '
+                   'bytes = WRITE_SIZE KiB x 1024; means per dispatch'}
+    if '--from-r01' in sys.argv:
+        old = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_final.json')))
+        for k, v in old.items():
+            base = k.split('<')[0]
+            if base in KERNELS:
+                out[k] = {'hbm_traffic_bytes_per_launch': v['hbm_traffic_bytes_per_launch'], 'FETCH_SIZE_KiB': v['FETCH_SIZE_KiB'],
+                          'WRITE_SIZE_KiB': v['WRITE_SIZE_KiB'], 'source_stamp': source_stamp(KERNELS[base]),
+                          'from': 'profiles/r01_pmc_final.json'}
+    else:
+        fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+        for k, v in fetch.items():
+            base = k.split('<')[0]
+            if base not in KERNELS or 'FETCH_SIZE' not in v:
+                continue
+            f = v['FETCH_SIZE']['mean']
+            w = write.get(k, {}).get('WRITE_SIZE', {}).get('mean', 0.0)
+            out[k] = {'hbm_traffic_bytes_per_launch': int(2 * f * 1024 + w * 1024), 'FETCH_SIZE_KiB': round(f, 1),
+                      'WRITE_SIZE_KiB': round(w, 1), 'dispatches_sampled': v['FETCH_SIZE']['dispatches'],
+                      'source_stamp': source_stamp(KERNELS[base])}
+    json.dump(out, open(PMC_FILE, 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -60,7 +60,14 @@ SIGNATURES = {
     'um_local_corr_with_flow': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
     'um_prop_local_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     'um_depth_corr_softmax': (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
+    'um_comm_unique_id': (_c_int, [_c_void_p]),
+    'um_comm_init_rank': (_c_int, [ctypes.POINTER(_c_void_p), _c_void_p, _c_int, _c_int]),
+    'um_comm_init_file': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_char_p, _c_int, _c_int, _c_int]),
+    'um_comm_world': (_c_int, [_c_void_p]),
+    'um_comm_destroy': (_c_int, [_c_void_p]),
+    'um_allgather_preds': (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

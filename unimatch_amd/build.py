@@ -11,10 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libunimatch_hip.so')
-SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip', 'microbench.hip']
+SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip', 'microbench.hip',
+           'rccl_gather.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
 # per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
-EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 
@@ -49,7 +50,7 @@ def build(force=False, verbose=False):
             subprocess.run(cmd, check=True, cwd=CSRC)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)

@@ -17,7 +17,9 @@
 // them and keep INDEPENDENT running maxima, merged once at the end (no cross-lane traffic per tile).
 // K tiles are staged through LDS (rows padded to 272 B: conflict-free ds_read_b128 A-fragments) with
 // the next tile's global loads in flight during the current tile's MFMAs.
+#include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "planes.h"
 
@@ -272,6 +274,320 @@ __global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// gsv3_kernel: the same computation, software-pipelined at instruction level.
+//
+// What round 1's profile said about gsv_kernel (profiles/r01_pmc_final.json): 6.7 VALU instructions per MFMA, every wave
+// 49 % of its cycles stalled at issue and the matrix pipe busy 49 % -- a wave issued its 48 MFMAs of a tile back to back
+// (32 cycles each with nothing else issued), then ~320 VALU instructions of softmax with the matrix pipe idle unless the
+// co-resident wave happened to be in its MFMA phase.  Here
+//   * the MFMAs of tile t+1 and the softmax of tile t form ONE instruction stream: after every MFMA come the 4-6 VALU /
+//     LDS / DMA instructions that fit in its 32-cycle shadow, pinned there with scheduling fences (two accumulator sets);
+//   * the softmax costs 4 VALU per score instead of 10: log2(e)/sqrt(C) is folded into the operand planes (sqrt of it on
+//     each side, so one set of planes still serves both directions of a bidirectional launch), the running offset M is
+//     the MFMAs' initial accumulator (srcC = a register block holding M), so p = exp2(acc) directly; the offset is
+//     renormalised lazily -- only when a tile's maximum exceeds M by more than 2^40 (exact: M stays an integer, every
+//     rescale factor is a power of two) -- on a separate, non-interleaved path that also serves masked (ragged / causal)
+//     tiles and the first tile; that decision needs the tile maximum, 16 v_max3 at the top of the iteration.
+// LDS: 2 K slots (tile t+1 is consumed while tile t+2 lands) + a 4-slot ring for the small value tiles, whose tile t is
+// still being read by the softmax while tile t+2 arrives.  One workgroup barrier per tile.
+template <int... Is, class F>
+__device__ __forceinline__ void gsv_static_for(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+#ifndef GSV3_FAST_LIMIT
+#define GSV3_FAST_LIMIT 40.f
+#endif
+
+template <class T, int NS, int NV, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
+    constexpr int TK = 64;
+    constexpr int PLANE = TK * 256;
+    constexpr int KSLOT = NS * PLANE;
+    constexpr int VSLOT = NV * TK * 4;
+    constexpr int VBASE = 2 * KSLOT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KSLOT + 4 * VSLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int b = blockIdx.y;
+    const int qwg = blockIdx.x * 128;
+    const int qi = qwg + wave * 32 + (lane & 31);
+
+    // ---- Q fragments (B operand of S^T = K . Q^T); the planes already carry sqrt(log2e / sqrt(C)) on both sides
+    i16x8 qf[NS][8];
+    {
+        const int qr = min(qi, a.Lq - 1);
+        const unsigned short* qb = a.qp + ((long)b * a.Lq + qr) * UM_CHANNELS + 8 * half;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.q_plane_stride + 16 * ks);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
+    }
+
+    int ntiles = (a.Lk + TK - 1) / TK;
+    if (CAUSAL) ntiles = min(ntiles, (min(qwg + 127, a.Lq - 1) / TK) + 1);
+    const int per = (ntiles + a.nsplit - 1) / a.nsplit;
+    const int tbeg = blockIdx.z * per, tend = min(ntiles, tbeg + per);
+
+    // ---- staging (as in gsv_kernel): wave w moves rows 16w .. 16w+15 of a tile, 4 rows per DMA instruction
+    const unsigned kbase_bytes = (unsigned)((long)b * a.Lk * UM_CHANNELS * 2);
+    const int srow = 16 * wave + (lane >> 4);
+    const int scp = lane & 15;
+    constexpr int NPIECE = 4 * NS;
+    auto k_piece = [&](int t, int i, unsigned char* slot) {
+        const int j = i / NS, pl = i % NS;
+        const int row = srow + 4 * j;
+        const int key = min(t * TK + row, a.Lk - 1);
+        const unsigned off = kbase_bytes + (unsigned)key * (UM_CHANNELS * 2) + ((scp ^ (row & 15)) << 4);
+        gsv_dma16(a.kp + pl * a.k_plane_stride, off, slot + pl * PLANE + (16 * wave + 4 * j) * 256);
+    };
+    const float* vbase = a.v + (long)b * a.v_batch_stride;
+    auto v_piece = [&](int t, unsigned char* vslot) {
+        if (wave < NV) {
+            const int key = min(t * TK + lane, a.Lk - 1);
+            gsv_dma4(vbase + wave * a.v_chan_stride, (unsigned)key * 4, vslot + wave * TK * 4);
+        }
+    };
+    auto stage_all = [&](int t, int i) {          // tile with local index i -> K slot i & 1, value slot i & 3
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) k_piece(t, pc, lds + (i & 1) * KSLOT);
+        v_piece(t, lds + VBASE + (i & 3) * VSLOT);
+    };
+
+    // Running softmax state, per lane (the two half-waves of a query keep independent states, merged at the end):
+    // l = sum 2^(score + Ms), acc = sum 2^(score + Ms) v.  Ms is an integer; cinit holds it as the MFMAs' initial accumulator.
+    float Ms = 0.f, l = 0.f;
+    float acc[NV];
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) acc[ch] = 0.f;
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+
+    int kaddr;
+    {
+        const int r = lane & 31, x = r & 15;
+        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
+    }
+
+    constexpr int MF = (NS == 2) ? 6 : 2;        // MFMAs per k-step (two 32-key sub-tiles)
+    constexpr int NM = 8 * MF;                   // MFMAs per tile
+
+    auto frag = [&](const unsigned char* cur, int ridx /* sub * NS + plane */, int ks) {
+        return *reinterpret_cast<const i16x8*>(cur + (ridx / NS) * (32 * 256) + (ridx % NS) * PLANE + (kaddr ^ (ks << 5)));
+    };
+    // one MFMA of the tile: index k = ks * MF + j
+    auto mfma_step = [&](auto kc, i16x8 (&fr)[2][2 * NS], f32x16& x0, f32x16& x1) {
+        constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF, bq = ks & 1;
+        if constexpr (NS == 2) {
+            // j: 0 lo0*qh  1 lo1*qh  2 hi0*ql  3 hi1*ql  4 hi0*qh  5 hi1*qh      (fr index = sub * 2 + plane)
+            constexpr int sub = j & 1, kpl = (j < 2) ? 1 : 0, qpl = (j == 2 || j == 3) ? 1 : 0;
+            f32x16& x = sub ? x1 : x0;
+            if constexpr (ks == 0 && j < 2) x = T::mfma(fr[bq][sub * 2 + kpl], qf[qpl][ks], cinit);
+            else x = T::mfma(fr[bq][sub * 2 + kpl], qf[qpl][ks], x);
+        } else {
+            constexpr int sub = j;
+            f32x16& x = sub ? x1 : x0;
+            if constexpr (ks == 0) x = T::mfma(fr[bq][sub], qf[0][ks], cinit);
+            else x = T::mfma(fr[bq][sub], qf[0][ks], x);
+        }
+    };
+
+    // ---- MFMAs of one tile with nothing interleaved (first tile, and after a slow-path softmax)
+    auto mfma_plain = [&](const unsigned char* cur, f32x16& x0, f32x16& x1) {
+        i16x8 fr[2][2 * NS];
+#pragma unroll
+        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF;
+            if constexpr (j < 2 * NS && ks + 1 < 8) fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
+            mfma_step(kc, fr, x0, x1);
+        });
+    };
+
+    // ---- slow path: masks, renormalisation of the offset, then the tile's softmax terms (not interleaved with MFMAs)
+    auto slow_update = [&](f32x16& y0, f32x16& y1, int t, const float* vt) {
+        const int kl = t * TK + 4 * half;
+        if (CAUSAL || t * TK + TK > a.Lk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kl + (r & 3) + 8 * (r >> 2);
+                y0[r] = ((key < a.Lk) && (!CAUSAL || key <= qi)) ? y0[r] : UM_NEG_MASK;
+                y1[r] = ((key + 32 < a.Lk) && (!CAUSAL || key + 32 <= qi)) ? y1[r] : UM_NEG_MASK;
+            }
+        }
+        float tm = fmaxf(y0[0], y1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(y0[r], y1[r]));
+        // the accumulators hold score + Ms.  New offset: the first live tile of a lane fixes it; later only upwards.
+        float d = (tm > -1.0e29f && (l == 0.f || tm > 0.f)) ? ceilf(tm) : 0.f;
+        const float f = fast_exp2(-d);
+        Ms -= d;
+        l *= f;
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[ch] *= f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 vv[NV];
+#pragma unroll
+                for (int ch = 0; ch < NV; ++ch)
+                    vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + sub * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = fast_exp2((sub ? y1[4 * g + i] : y0[4 * g + i]) - d);
+                    l += p;
+#pragma unroll
+                    for (int ch = 0; ch < NV; ++ch) acc[ch] = __builtin_fmaf(p, vv[ch][i], acc[ch]);
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = Ms;
+    };
+
+    // value group G (4 scores) of a tile: G >> 2 = sub-tile, G & 3 = register group
+    auto vload = [&](const float* vt, int G, f32x4 (&vv)[NV]) {
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch)
+            vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + (G >> 2) * 32 + 8 * (G & 3) + 4 * half);
+    };
+    auto score = [&](auto sc, const f32x16& y0, const f32x16& y1, f32x4 (&vv)[2][NV]) {
+        constexpr int S = decltype(sc)::value, sub = S >> 4, r = S & 15, G = S >> 2, i = S & 3;
+        const float p = fast_exp2(sub ? y1[r] : y0[r]);
+        l += p;
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[ch] = __builtin_fmaf(p, vv[G & 1][ch][i], acc[ch]);
+    };
+
+    // ---- fast path: softmax terms of tile t (accumulators y) under the MFMAs of tile t+1 (accumulators x).
+    // One basic block (STAGING is a compile-time flag: a branch around the DMA pieces would split it, and the softmax
+    // arithmetic -- pure, needed only at the end -- would be sunk out of the MFMA shadows); after every MFMA the state is
+    // passed through an empty volatile asm, which pins that gap's VALU work between two scheduling fences.
+    auto fused = [&](auto staging_c, const unsigned char* cur /* K slot of t+1 */, f32x16& x0, f32x16& x1, const f32x16& y0,
+                     const f32x16& y1, const float* vt, int tnext2, int inext2) {
+        constexpr bool STAGING = decltype(staging_c)::value;
+        i16x8 fr[2][2 * NS];
+        f32x4 vv[2][NV];
+#pragma unroll
+        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        vload(vt, 0, vv[0]);
+        unsigned char* kdst = lds + (inext2 & 1) * KSLOT;
+        unsigned char* vdst = lds + VBASE + (inext2 & 3) * VSLOT;
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF;
+            mfma_step(kc, fr, x0, x1);
+            // fillers in this MFMA's shadow
+            if constexpr (j < 2 * NS && ks + 1 < 8) fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
+            constexpr int S0 = K * 32 / NM, S1 = (K + 1) * 32 / NM;
+            gsv_static_for(std::make_integer_sequence<int, S1 - S0>{}, [&](auto dc) {
+                constexpr int S = S0 + decltype(dc)::value;
+                if constexpr ((S & 3) == 0 && (S >> 2) + 1 < 8) vload(vt, (S >> 2) + 1, vv[((S >> 2) + 1) & 1]);
+                score(std::integral_constant<int, S>{}, y0, y1, vv);
+            });
+            if constexpr (S1 > S0) {
+                if constexpr (NV == 2) asm volatile("" : "+v"(l), "+v"(acc[0]), "+v"(acc[NV - 1]));
+                else asm volatile("" : "+v"(l), "+v"(acc[0]));
+            }
+            constexpr int STEP = NM / (NPIECE + 1);
+            if constexpr (STAGING && K % STEP == 0 && K / STEP <= NPIECE) {
+                if constexpr (K / STEP < NPIECE) k_piece(tnext2, K / STEP, kdst);
+                else v_piece(tnext2, vdst);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto fast_update = [&](const f32x16& y0, const f32x16& y1, const float* vt) {      // last tile: nothing left to overlap
+        f32x4 vv[2][NV];
+        vload(vt, 0, vv[0]);
+        gsv_static_for(std::make_integer_sequence<int, 32>{}, [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if constexpr ((S & 3) == 0 && (S >> 2) + 1 < 8) vload(vt, (S >> 2) + 1, vv[((S >> 2) + 1) & 1]);
+            score(sc, y0, y1, vv);
+        });
+    };
+
+    const int n = tend - tbeg;
+    f32x16 xa0, xa1, xb0, xb1;
+    if (n > 0) {
+        stage_all(tbeg, 0);
+        if (n > 1) stage_all(tbeg + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mfma_plain(lds, xa0, xa1);
+    }
+    // iteration i: y = scores of tile i (complete), x = accumulators of tile i+1
+    auto iteration = [&](int i, f32x16& y0, f32x16& y1, f32x16& x0, f32x16& x1) {
+        const int t = tbeg + i;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile i+1 has landed
+        __syncthreads();                                            // ... everyone's; and everyone is done reading K slot i & 1
+        const float* vt = reinterpret_cast<const float*>(lds + VBASE + (i & 3) * VSLOT);
+        const unsigned char* knext = lds + ((i + 1) & 1) * KSLOT;
+        const bool staging = i + 2 < n;
+        float tm = fmaxf(fmaxf(y0[0], y0[1]), y0[2]);
+#pragma unroll
+        for (int r = 3; r < 16; ++r) tm = fmaxf(tm, y0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, y1[r]);
+        const bool masked = CAUSAL || (t * TK + TK > a.Lk);
+        const bool slow = masked || __builtin_amdgcn_ballot_w64(tm > GSV3_FAST_LIMIT || l == 0.f) != 0;
+        if (slow) {
+            if (staging) stage_all(t + 2, i + 2);
+            slow_update(y0, y1, t, vt);
+            if (i + 1 < n) mfma_plain(knext, x0, x1);
+        } else if (staging) {
+            fused(std::true_type{}, knext, x0, x1, y0, y1, vt, t + 2, i + 2);
+        } else if (i + 1 < n) {
+            fused(std::false_type{}, knext, x0, x1, y0, y1, vt, t + 2, i + 2);
+        } else {
+            fast_update(y0, y1, vt);
+        }
+    };
+    for (int i = 0; i < n; i += 2) {
+        iteration(i, xa0, xa1, xb0, xb1);
+        if (i + 1 < n) iteration(i + 1, xb0, xb1, xa0, xa1);
+    }
+
+    // ---- merge the two half-waves' partial softmaxes and write (M = Ms: p = 2^(score + M)) ------------------
+    const float M = (l == 0.f) ? 3.0e38f : Ms;                     // a lane that met no valid key must not set the common offset
+    const float M2 = __shfl_xor(M, 32);
+    const float l2 = __shfl_xor(l, 32);
+    const float MM = fminf(M, M2);
+    const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
+    const float lt = l * f1 + l2 * f2;
+    if (a.nsplit > 1) {
+        float* pr = a.partial + (((long)blockIdx.z * gridDim.y + b) * a.Lq + qi) * (2 + NV);
+        if (half == 0 && qi < a.Lq) {
+            pr[0] = MM;
+            pr[1] = lt;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) {
+            const float a2 = __shfl_xor(acc[ch], 32);
+            if (half == 0 && qi < a.Lq) pr[2 + ch] = acc[ch] * f1 + a2 * f2;
+        }
+        return;
+    }
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) {
+        const float a2 = __shfl_xor(acc[ch], 32);
+        const float at = acc[ch] * f1 + a2 * f2;
+        if (half == 0 && qi < a.Lq) {
+            float r = a.alpha * (at / lt);
+            if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi];
+            a.out[((long)b * NV + ch) * a.Lq + qi] = r;
+        }
+    }
+}
+
 // merge the per-split partial softmaxes: out = alpha * sum_s(acc_s 2^(M-M_s)) / sum_s(l_s 2^(M-M_s)) + beta * v[query]
 template <int NV>
 __global__ void gsv_combine_kernel(GsvArgs a, int nbatch) {
@@ -326,6 +642,14 @@ static int gsv_choose_split(int qtiles, int nbatch, int ktiles) {
     return best;
 }
 
+// UM_GSV_V2=1 selects round 1's phase-structured kernel (same-box A/B runs); default: the software-pipelined gsv3_kernel,
+// whose operand planes carry sqrt(log2(e) / sqrt(C)) on both sides.
+static bool gsv_use_v2() {
+    static const int v = [] { const char* e = getenv("UM_GSV_V2"); return (e && *e == '1') ? 1 : 0; }();
+    return v != 0;
+}
+static float gsv_plane_scale(float scale_log2) { return gsv_use_v2() ? 1.f : sqrtf(scale_log2); }
+
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
     const int qtiles = (a.Lq + 127) / 128;
@@ -334,10 +658,16 @@ static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hi
     dim3 grid(qtiles, nbatch, a.nsplit), block(256);
     {
         ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
-        if (mode == 0)
-            hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((gsv_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
+        if (gsv_use_v2()) {
+            if (mode == 0)
+                hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL((gsv_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
+        } else if (mode == 0) {
+            hipLaunchKernelGGL((gsv3_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((gsv3_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.nsplit > 1) {
@@ -395,8 +725,9 @@ extern "C" int um_global_corr_softmax_flow(const float* f0, const float* f1, flo
     float* grid = (float*)(ws + 2 * pb);
     float* partial = (float*)(ws + 2 * pb + align256((size_t)L * 2 * sizeof(float)));
     hipError_t e;
-    if ((e = launch_split_planes(f0, p0, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
-    if ((e = launch_split_planes(f1, p1, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
+    const float pscale = gsv_plane_scale(UM_LOG2E / sqrtf((float)channels));
+    if ((e = launch_split_planes(f0, p0, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_split_planes(f1, p1, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fill_grid_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, stream, grid, h, w);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
 
@@ -435,8 +766,9 @@ extern "C" int um_global_corr_softmax_stereo(const float* f0, const float* f1, f
     unsigned short* p1 = (unsigned short*)(ws + pb);
     float* grid = (float*)(ws + 2 * pb);
     hipError_t e;
-    if ((e = launch_split_planes(f0, p0, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
-    if ((e = launch_split_planes(f1, p1, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
+    const float pscale = gsv_plane_scale(UM_LOG2E / sqrtf((float)channels));
+    if ((e = launch_split_planes(f0, p0, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_split_planes(f1, p1, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
     // x table = first w entries of a 1 x w pixel grid
     hipLaunchKernelGGL(fill_grid_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, stream, grid, 1, w);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
@@ -473,8 +805,9 @@ extern "C" int um_prop_global_attn(const float* q, const float* k, const float* 
     unsigned short* pk = (unsigned short*)(ws + pb);
     float* partial = (float*)(ws + 2 * pb + align256((size_t)L * 2 * sizeof(float)));
     hipError_t e;
-    if ((e = launch_split_planes(q, pq, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
-    if ((e = launch_split_planes(k, pk, batch * L, 1.f, mode, stream)) != hipSuccess) return (int)e;
+    const float pscale = gsv_plane_scale(UM_LOG2E / sqrtf((float)channels));
+    if ((e = launch_split_planes(q, pq, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_split_planes(k, pk, batch * L, pscale, mode, stream)) != hipSuccess) return (int)e;
     GsvArgs a;
     a.qp = pq;
     a.kp = pk;

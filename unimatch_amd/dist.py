@@ -8,7 +8,11 @@ no inference-time parallelism at all (its only collective is DDP's gradient all-
 main_flow.py:188-191); its process-group bring-up role (utils/dist_utils.py:12-30) is taken by
 ``init_distributed`` below.
 """
+import ctypes
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -30,6 +34,88 @@ def init_distributed(backend=None):
         kwargs = {'device_id': device} if backend == 'nccl' else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, device
+
+
+class RcclGather:
+    """The prediction all-gather through the library's own C ABI (``um_allgather_preds`` = ``ncclAllGather`` on the
+    caller's stream, include/unimatch_hip.h) -- ``torch.distributed`` is then only the launcher.
+
+    Bootstrap: ``id_file`` (torch-free: rank 0 publishes the 128-byte unique id in a file every rank of the node can
+    read), else the id travels through the already initialised ``torch.distributed`` group (any backend)."""
+
+    def __init__(self, rank, world, device, id_file=None, timeout=120):
+        from . import _abi
+        self._abi, self.lib = _abi, _abi.load()
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):                       # ncclCommInitRank binds the current device
+            if id_file:
+                code = self.lib.um_comm_init_file(ctypes.byref(self.comm), os.fsencode(id_file), rank, world, timeout)
+            else:
+                uid = (ctypes.c_ubyte * _abi.COMM_ID_BYTES)()
+                if rank == 0:
+                    _abi.check(self.lib.um_comm_unique_id(uid), 'um_comm_unique_id')
+                box = [bytes(uid)]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                uid = (ctypes.c_ubyte * _abi.COMM_ID_BYTES).from_buffer_copy(box[0])
+                code = self.lib.um_comm_init_rank(ctypes.byref(self.comm), uid, rank, world)
+        _abi.check(code, 'um_comm_init')
+
+    def ranks(self):
+        return self.lib.um_comm_world(self.comm)
+
+    def all_gather(self, send, recv=None, stream=None):
+        """send: contiguous fp32 CUDA tensor; returns ``[world, *send.shape]`` (enqueued on ``stream`` / the current one)."""
+        assert send.is_cuda and send.dtype == torch.float32 and send.is_contiguous()
+        if recv is None:
+            recv = torch.empty(self.world, *send.shape, dtype=torch.float32, device=send.device)
+        assert recv.is_contiguous() and recv.numel() == self.world * send.numel()
+        st = stream if stream is not None else torch.cuda.current_stream(send.device)
+        with torch.cuda.device(send.device):
+            self._abi.check(self.lib.um_allgather_preds(self.comm, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                        st.cuda_stream), 'um_allgather_preds')
+        return recv
+
+    def close(self):
+        if self.comm:
+            self.lib.um_comm_destroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
+_GATHER = None
+
+
+def rccl_gather(device=None):
+    """The process-wide RcclGather of an initialised multi-rank job on GPUs (created on first use)."""
+    global _GATHER
+    if _GATHER is None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        _GATHER = RcclGather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
+    return _GATHER
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script, script_args, nproc, need_gpus=True, env=None):
+    """Run ``script`` as ``nproc`` ranks of one node (what ``python bench.py --gpus N`` does when it was not started
+    by a launcher): ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``.
+    Fails loudly -- never silently measures fewer GPUs -- when the node has fewer than ``nproc`` GPUs.
+    Returns the launcher's exit code."""
+    if need_gpus:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < nproc:
+            raise SystemExit(f'{os.path.basename(script)}: {nproc} GPUs requested but this node exposes {have}')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script] + list(script_args)
+    e = dict(os.environ if env is None else env)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')                 # dmabuf IPC only on these hosts (RCCL needs it)
+    return subprocess.call(cmd, env=e)
 
 
 def shard_bounds(batch, rank, world):
@@ -65,8 +151,11 @@ def all_gather_predictions(local, batch, rank, world, parts=1):
         pad = torch.zeros(parts, bmax - counts[rank], *tail, dtype=local.dtype, device=local.device)
         mine = torch.cat([mine, pad], 1)
     mine = mine.contiguous()
-    out = torch.empty(world * parts, bmax, *tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, mine)          # concatenation along dim 0, rank major
+    if mine.is_cuda and mine.dtype == torch.float32:
+        out = rccl_gather(mine.device).all_gather(mine)            # the library's own ncclAllGather, current stream
+    else:                                                           # CPU tensors (gloo tests): the launcher's group
+        out = torch.empty(world * parts, bmax, *tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, mine)      # concatenation along dim 0, rank major
     out = out.view(world, parts, bmax, *tail)
     pieces = [out[r, :, :counts[r]] for r in range(world)]           # each [parts, b_r, ...]
     full = torch.cat(pieces, 1)                                       # [parts, batch, ...]

@@ -486,6 +486,8 @@ class UniMatch(nn.Module):
                         flow = flow + delta
                     if task == 'stereo':
                         flow = flow.clamp(min=0)
+                    if self.debug_taps is not None:
+                        self.debug_taps[f'flow_it{it}'] = flow
                     if it == num_reg_refine - 1:
                         if task == 'depth':
                             pad = torch.cat([flow, torch.zeros_like(flow)], 1)
