@@ -22,6 +22,12 @@
  *                      (~2^-22 relative operand error: meets the fp32 reference to its own noise floor)
  *       UM_MODE_FAST   bf16 operands, 1 MFMA product per tile, fp32 accumulate
  *     Softmax, accumulators and all non-MFMA kernels are fp32 in both modes.
+ *   - Operand range (UM_MODE_EXACT): x = hi + lo with hi = rn_fp16(x), lo = rn_fp16(x - hi) gives 22 significant bits
+ *     while lo stays in fp16's normal range, i.e. for element magnitudes in about [2^-3, 2^15]; below, the absolute
+ *     error floor is 2^-25 (fp16 subnormal granularity), above 65504 the hi plane saturates to inf.  Weights are
+ *     pre-scaled by 2^wshift (2^10) so that |w| in [2^-13, 2^5) is covered.  The model's activations on this path are
+ *     O(1)..O(10) (LayerNorm / InstanceNorm outputs, features of std 1..4); tests/test_hip_parity_gpu.py sweeps
+ *     0.1 .. 100.  There is no per-tensor rescaling: callers with other magnitudes scale by a power of two around the call.
  */
 #ifndef UNIMATCH_HIP_H
 #define UNIMATCH_HIP_H
@@ -133,6 +139,15 @@ int um_linear_fwd(const float* a0, const float* a1, const void* a_planes, const 
                   int m, int n, int k, int wshift, int epilogue, void* out,
                   const float* gamma, const float* beta, const float* residual, float eps,
                   int mode, void* stream);
+
+/* nn.Linear WITH bias -- the propagation layer's q / k projections (unimatch/attention.py:196-205 global, :229-232 local):
+ *     C = (A . W^T) * out_mul + bias * bias_mul
+ * input: exactly one of a0 (fp32 [M,K]) | a_planes ([NS][M][K]);  output: exactly one of out_planes ([NS][M][N], feeds
+ * um_prop_global_attn_planes) | out_f32 ([M,N], feeds um_prop_local_attn).  w_planes / wshift as for um_linear_fwd; bias: fp32
+ * [N], 16-byte aligned.  With A already scaled by s (planes carrying um_global_corr_plane_scale()), out_mul = 1 and
+ * bias_mul = s give s * (W a + b). */
+int um_linear_bias_fwd(const float* a0, const void* a_planes, const void* w_planes, const float* bias, int m, int n, int k,
+                       int wshift, float out_mul, float bias_mul, void* out_planes, float* out_f32, int mode, void* stream);
 
 /* Whole FFN of a Transformer layer in ONE kernel:
  *     out = x + LayerNorm( W2 . gelu( W1 . [x | y] ) )          (unimatch/transformer.py:141-144, mlp :44-50)
@@ -251,6 +266,13 @@ int um_global_corr_softmax_stereo(const float* f0, const float* f1, float* disp,
 int um_prop_global_attn(const float* q, const float* k, const float* value, float* out,
                         int batch, int h, int w, int channels, int value_channels,
                         int mode, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on operands that are already MFMA planes ([NS][batch*h*w][128]) carrying um_global_corr_plane_scale(channels) on
+ * both q and k (= sqrt(log2(e) / sqrt(C)): the kernels take the softmax logit in log2 units straight from the MFMA) -- the
+ * output of um_linear_bias_fwd(out_planes).  Workspace as um_global_corr_workspace_bytes(). */
+float um_global_corr_plane_scale(int channels);
+int um_prop_global_attn_planes(const void* q_planes, const void* k_planes, const float* value, float* out, int batch, int h,
+                               int w, int channels, int value_channels, int mode, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Local-window kernels (fp32 VALU, wavefront-shuffle reductions; `mode` does not apply).

@@ -29,6 +29,7 @@ SIGNATURES = {
     'um_planes_bytes': (_c_size_t, [ctypes.c_long, _c_int, _c_int]),
     'um_weight_planes': (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p]),
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),
+    'um_linear_bias_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_void_p] * 2 + [_c_int, _c_void_p]),
     'um_ffn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
     'um_conv2d_fwd': (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_void_p]),
     'um_conv2d_ex': (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p,
@@ -56,6 +57,8 @@ SIGNATURES = {
     'um_global_corr_softmax_flow': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_global_corr_softmax_stereo': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_prop_global_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_global_corr_plane_scale': (ctypes.c_float, [_c_int]),
+    'um_prop_global_attn_planes': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_local_corr_softmax': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
     'um_local_corr_with_flow': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
     'um_prop_local_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
         for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(y0[r], y1[r]));
         // the accumulators hold score + Ms.  New offset: the first live tile of a lane fixes it; later only upwards.
         float d = (tm > -1.0e29f && (l == 0.f || tm > 0.f)) ? ceilf(tm) : 0.f;
-        const float f = fast_exp2(-d);
+        const float f = (d > 0.f) ? fast_exp2(-d) : 1.f;           // d < 0 only while the state is still empty (l == acc == 0)
         Ms -= d;
         l *= f;
 #pragma unroll
@@ -824,5 +824,44 @@ extern "C" int um_prop_global_attn(const float* q, const float* k, const float* 
         e = launch_gsv<2, false>(a, batch, mode, partial, stream);
     else
         e = launch_gsv<1, false>(a, batch, mode, partial, stream);
+    return (int)e;
+}
+
+// The factor the operand planes of this file's kernels carry on BOTH sides (q and k): sqrt(log2(e) / sqrt(C)), so that the MFMA
+// result is the softmax logit in log2 units.  (1 when UM_GSV_V2=1 selects the round-1 kernel, which scales the scores instead.)
+extern "C" float um_global_corr_plane_scale(int channels) {
+    return channels > 0 ? gsv_plane_scale(UM_LOG2E / sqrtf((float)channels)) : 0.f;
+}
+
+// um_prop_global_attn on operands that are ALREADY planes carrying um_global_corr_plane_scale() -- the output of
+// um_linear_bias_fwd(out_planes) -- so the propagation layer's q / k never exist in fp32 (attention.py:196-213).
+extern "C" int um_prop_global_attn_planes(const void* q_planes, const void* k_planes, const float* value, float* out, int batch,
+                                          int h, int w, int channels, int value_channels, int mode, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long L = (long)h * w;
+    const size_t need = um_global_corr_workspace_bytes(batch, (int)L, channels, mode);
+    if (int e = check_common(q_planes, k_planes, out, batch, h, w, channels, mode, workspace, workspace_bytes, need)) return e;
+    if (!value || (value_channels != 1 && value_channels != 2)) {
+        um_set_error("value_channels=%d: the reference propagates flow (2) or disparity/depth (1)", value_channels);
+        return -1;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    const size_t pb = align256(planes_bytes(batch * L, mode));
+    float* partial = (float*)(ws + 2 * pb + align256((size_t)L * 2 * sizeof(float)));
+    GsvArgs a;
+    a.qp = (const unsigned short*)q_planes;
+    a.kp = (const unsigned short*)k_planes;
+    a.q_plane_stride = a.k_plane_stride = batch * L * UM_CHANNELS;
+    a.v = value;
+    a.v_batch_stride = value_channels * L;
+    a.v_chan_stride = L;
+    a.out = out;
+    a.Lq = a.Lk = (int)L;
+    a.scale_log2 = UM_LOG2E / sqrtf((float)channels);
+    a.alpha = 1.f;
+    a.beta = 0.f;
+    hipError_t e = (value_channels == 2) ? launch_gsv<2, false>(a, batch, mode, partial, stream)
+                                         : launch_gsv<1, false>(a, batch, mode, partial, stream);
     return (int)e;
 }

@@ -24,7 +24,7 @@
 #include "planes.h"
 
 enum { A_F32 = 0, A_CONCAT = 1, A_PLANES = 2 };
-enum { EPI_PLANES = 0, EPI_LN = 1, EPI_GELU_PLANES = 2 };
+enum { EPI_PLANES = 0, EPI_LN = 1, EPI_GELU_PLANES = 2, EPI_F32 = 3 };
 
 struct LinArgs {
     const float* a0;              // A_F32: [M, K];  A_CONCAT: [M, K/2] (first half of K)
@@ -42,6 +42,8 @@ struct LinArgs {
     const float* beta;
     const float* residual;        // EPI_LN: optional [M, N]
     float eps;
+    const float* bias;            // optional [N]: C = A.W^T * out_scale + bias * bias_scale  (nn.Linear with bias)
+    float bias_scale;
 };
 
 __device__ __forceinline__ void lin_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -182,8 +184,31 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] *= a.out_scale;
+    if (a.bias) {                                                 // wave-uniform; accumulator row = output feature
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n0 + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = __builtin_fmaf(bb[i], a.bias_scale, acc[nt][4 * g + i]);
+            }
+    }
 
-    if (EPI == EPI_PLANES || EPI == EPI_GELU_PLANES) {
+    if (EPI == EPI_F32) {                                         // plain fp32 result (the propagation layer's local q / k)
+        if (valid) {
+            float* ob = a.outf + (long)tok * a.N + n0 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = acc[nt][4 * g + i];
+                    *reinterpret_cast<f32x4*>(ob + 32 * nt + 8 * g) = y;
+                }
+        }
+    } else if (EPI == EPI_PLANES || EPI == EPI_GELU_PLANES) {
         // The accumulator layout gives every lane 8-byte pieces of 32 different token rows: written directly that is
         // 32 partial cache lines per store instruction (measured: the stores cost as much as the whole main loop).
         // The tile goes through the idle staging ring instead -- every wave transposes its own 32 x 128 block, one
@@ -339,6 +364,8 @@ extern "C" int um_linear_fwd(const float* a0, const float* a1, const void* a_pla
     a.beta = beta;
     a.residual = residual;
     a.eps = eps;
+    a.bias = nullptr;
+    a.bias_scale = 0.f;
     hipError_t e;
     if (a_planes) {
         if (epilogue == EPI_LN) e = launch_linear<A_PLANES, EPI_LN>(a, mode, stream);
@@ -353,5 +380,53 @@ extern "C" int um_linear_fwd(const float* a0, const float* a1, const void* a_pla
         else if (epilogue == EPI_PLANES) e = launch_linear<A_F32, EPI_PLANES>(a, mode, stream);
         else e = launch_linear<A_F32, EPI_GELU_PLANES>(a, mode, stream);
     }
+    return (int)e;
+}
+
+// nn.Linear WITH bias (the propagation layer's projections, unimatch/attention.py:196-205, 229-232):
+//     C = (A . W^T) * out_mul + bias * bias_mul      ->  operand planes [NS][M][N]  or  fp32 [M, N]
+// out_mul / bias_mul let the caller hand the result to um_prop_global_attn_planes() already carrying the plane factor.
+extern "C" int um_linear_bias_fwd(const float* a0, const void* a_planes, const void* w_planes, const float* bias, int m, int n,
+                                  int k, int wshift, float out_mul, float bias_mul, void* out_planes, float* out_f32, int mode,
+                                  void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m <= 0 || (m + 127) / 128 > 65535 || n <= 0 || k <= 0 || n % 128 != 0 || k % 32 != 0 || !w_planes || !bias ||
+        (mode != 0 && mode != 1) || wshift < 0 || wshift > 14) {
+        um_set_error("um_linear_bias_fwd: bad argument (m=%d n=%d k=%d wshift=%d: n must be a multiple of 128, k of 32)", m, n, k, wshift);
+        return -1;
+    }
+    if (((a0 != nullptr) + (a_planes != nullptr)) != 1 || ((out_planes != nullptr) + (out_f32 != nullptr)) != 1) {
+        um_set_error("um_linear_bias_fwd: give exactly one input (a0 | a_planes) and exactly one output (out_planes | out_f32)");
+        return -1;
+    }
+    if (((uintptr_t)bias & 15) != 0) {
+        um_set_error("um_linear_bias_fwd: bias must be 16-byte aligned");
+        return -1;
+    }
+    if ((long)m * k * 2 >= (1L << 32) || (long)n * k * 2 >= (1L << 32)) {
+        um_set_error("um_linear_bias_fwd: operand planes beyond 4 GiB are not addressable by this kernel");
+        return -4;
+    }
+    LinArgs a;
+    a.a0 = a0;
+    a.a1 = nullptr;
+    a.ap = (const unsigned short*)a_planes;
+    a.a_plane_stride = (long)m * k;
+    a.wp = (const unsigned short*)w_planes;
+    a.w_plane_stride = (long)n * k;
+    a.M = m;
+    a.N = n;
+    a.K = k;
+    a.out_scale = ldexpf(1.f, -wshift) * out_mul;
+    a.outp = (unsigned short*)out_planes;
+    a.out_plane_stride = (long)m * n;
+    a.outf = out_f32;
+    a.gamma = a.beta = a.residual = nullptr;
+    a.eps = 0.f;
+    a.bias = bias;
+    a.bias_scale = bias_mul;
+    hipError_t e;
+    if (a_planes) e = out_planes ? launch_linear<A_PLANES, EPI_PLANES>(a, mode, stream) : launch_linear<A_PLANES, EPI_F32>(a, mode, stream);
+    else e = out_planes ? launch_linear<A_F32, EPI_PLANES>(a, mode, stream) : launch_linear<A_F32, EPI_F32>(a, mode, stream);
     return (int)e;
 }

@@ -204,10 +204,18 @@ class SelfAttnPropagation(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, ops, tok0, flow, h, w, local_window_attn=False, local_window_radius=1):
-        q = self.q_proj(tok0)
+        if hasattr(ops, 'linear_bias') and tok0.is_cuda:              # the library's own biased Linear (um_linear_bias_fwd)
+            if not local_window_attn:
+                # reference quirk kept on purpose: the global path projects the *query* again (attention.py:198-205)
+                return ops.prop_global_projected(tok0, self.q_proj, self.k_proj, flow, h, w)
+            b, l, c = tok0.shape
+            x = tok0.reshape(b * l, c)
+            q = ops.linear_bias(x, self.q_proj.weight, self.q_proj.bias).view(b, l, c)
+            k = ops.linear_bias(x, self.k_proj.weight, self.k_proj.bias).view(b, l, c)
+            return ops.prop_local(q, k, flow, h, w, local_window_radius)
+        q = self.q_proj(tok0)                                         # injected CPU oracle backend (host-logic tests)
         if local_window_attn:
             return ops.prop_local(q, self.k_proj(tok0), flow, h, w, local_window_radius)
-        # reference quirk kept on purpose: the global path projects the *query* again (attention.py:198-205)
         return ops.prop_global(q, self.k_proj(q), flow, h, w)
 
 
@@ -272,6 +280,8 @@ class UniMatch(nn.Module):
         self._precision = 'exact'
         self._pos_cache = {}
         self.debug_taps = None            # set to a dict to collect named intermediates (diagnostics only)
+        self.check_weights = False        # True: fingerprint the parameters every forward (see _check_weight_print)
+        self._weight_print = None
 
     # ------------------------------------------------------------------ hot-path backend
     def set_precision(self, precision):
@@ -279,6 +289,36 @@ class UniMatch(nn.Module):
         self._precision = precision
         self._ops = None
         return self
+
+    def invalidate_weights(self):
+        """Drop the cached MFMA operand planes of the weights.  Needed only after an in-place edit through ``.data``
+        (``p.data.mul_(2)`` changes neither the tensor's identity, version nor address); ``load_state_dict``, ``.to()`` /
+        ``.float()`` / ``.cuda()`` and ``p.data = new`` are detected without it."""
+        if self._ops is not None:
+            self._ops.invalidate_weights()
+        self._weight_print = None
+        return self
+
+    def _apply(self, fn, *args, **kwargs):            # .to() / .cuda() / .float(): parameters move, caches must not survive
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weights()
+        self._pos_cache = {}
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weights()
+        return out
+
+    def _check_weight_print(self):
+        """check_weights=True: a per-forward fingerprint of all parameters (one fused norm, one host sync) that catches
+        in-place ``.data`` edits automatically -- off by default because the sync serialises back-to-back forwards."""
+        params = [p.detach() for p in self.parameters()]
+        fp = torch.stack(torch._foreach_norm(params)).double().cpu()
+        if self._weight_print is not None and not torch.equal(fp, self._weight_print):
+            if self._ops is not None:
+                self._ops.invalidate_weights()
+        self._weight_print = fp
 
     def bind_ops(self, ops):
         """Install a hot-path backend explicitly (tests inject the CPU oracle here)."""
@@ -360,6 +400,8 @@ class UniMatch(nn.Module):
         else:
             assert len(attn_splits_list) == len(corr_radius_list) == len(prop_radius_list) == self.num_scales
         ops = self.ops
+        if self.check_weights:
+            self._check_weight_print()
         attn_type = attn_type if attn_type is not None else ''
         dev = img0.device
 

@@ -115,11 +115,18 @@ class HipOps:
         """Cached value for these tensor OBJECTS at their current versions.  Keyed by identity and validated through weak
         references: a ``data_ptr`` key is wrong for temporaries (the allocator hands a freed weight's address to the next
         tensor of the same shape)."""
-        key = (tag,) + tuple((id(t), t._version) for t in tensors)
+        # identity + autograd version + storage address + device + dtype: `p.data = ...`, `.to(device)`, `.float()` keep id and
+        # version but move / retype the storage; an IN-PLACE edit through `.data` (`p.data.mul_(2)`) changes none of these and
+        # needs invalidate_weights() (UniMatch.invalidate_weights(), or check_weights=True for a per-forward fingerprint)
+        key = (tag,) + tuple((id(t), t._version, t.data_ptr(), str(t.device), t.dtype) for t in tensors)
         hit = self._wcache.get(key)
         if hit is not None and all(r() is t for r, t in zip(hit[0], tensors)):
             return key, hit[1]
         return key, None
+
+    def invalidate_weights(self):
+        """Forget every cached operand plane (call after editing weights in place through ``.data``)."""
+        self._wcache.clear()
 
     def _cache_put(self, key, tensors, value):
         if len(self._wcache) > 256:
@@ -566,6 +573,52 @@ class HipOps:
             _ptr(q), _ptr(k), _ptr(value), _ptr(out), b, h, w, c, vch, self.mode,
             _ptr(ws), ws.numel(), _stream()), meta)
         _abi.check(code, 'um_prop_global_attn')
+        return out
+
+    def linear_bias(self, a, weight, bias, out_mul=1.0, bias_mul=1.0, planes=False, a_planes_k=None):
+        """``nn.Linear`` with bias on ``um_linear_bias_fwd``: ``(A . W^T) * out_mul + bias * bias_mul`` as fp32 ``[M, N]`` or
+        (``planes``) as MFMA operand planes.  ``a``: fp32 ``[M, K]``, or planes with ``a_planes_k`` columns."""
+        wp, n, k = self.weight_planes((weight,))
+        if a_planes_k is not None:
+            m = a.numel() // (2 * self.nplanes * a_planes_k)
+            src = (None, _ptr(a))
+        else:
+            m = a.shape[0]
+            self._check_rows('a', a, k)
+            src = (_ptr(a), None)
+        bias = bias.detach()
+        if not (bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == n):
+            raise ValueError(f'linear_bias: expected a contiguous CUDA float32 bias of {n} elements')
+        if planes:
+            out = torch.empty(self.lib.um_planes_bytes(m, n, self.mode), dtype=torch.uint8, device=a.device)
+            dst = (_ptr(out), None)
+        else:
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+            dst = (None, _ptr(out))
+        code = self._launch('linear', lambda: self.lib.um_linear_bias_fwd(
+            src[0], src[1], _ptr(wp), _ptr(bias), m, n, k, self.WSHIFT, float(out_mul), float(bias_mul), dst[0], dst[1],
+            self.mode, _stream()), {'flops': 2.0 * m * n * k})
+        _abi.check(code, 'um_linear_bias_fwd')
+        return out
+
+    def prop_global_projected(self, tokens, q_proj, k_proj, value, h, w):
+        """The whole global propagation layer (attention.py:196-213): ``q = Wq x + bq``, ``k = Wk q + bk`` (of q -- the
+        reference's quirk), ``softmax(q k^T / sqrt(C)) value``.  q and k go from the projection kernels to the attention
+        kernel as operand planes; no library GEMM, no fp32 q / k."""
+        b, l, c = tokens.shape
+        _check_tokens('tokens', tokens, tokens=h * w)
+        _check_map('value', value, b, h, w)
+        ps = self.lib.um_global_corr_plane_scale(c)
+        x = tokens.reshape(b * l, c)
+        qp = self.linear_bias(x, q_proj.weight, q_proj.bias, out_mul=ps, bias_mul=ps, planes=True)
+        kp = self.linear_bias(qp, k_proj.weight, k_proj.bias, out_mul=1.0, bias_mul=ps, planes=True, a_planes_k=c)
+        out = torch.empty_like(value)
+        ws = self._ws(self.lib.um_global_corr_workspace_bytes(b, l, c, self.mode), tokens.device)
+        vch = value.shape[1]
+        meta = {'flops': b * (2.0 * l * l * c + 2.0 * l * l * vch), 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l * vch}
+        code = self._launch('prop_global', lambda: self.lib.um_prop_global_attn_planes(
+            _ptr(qp), _ptr(kp), _ptr(value), _ptr(out), b, h, w, c, vch, self.mode, _ptr(ws), ws.numel(), _stream()), meta)
+        _abi.check(code, 'um_prop_global_attn_planes')
         return out
 
     # ------------------------------------------------------------------ local kernels (fp32)
