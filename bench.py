@@ -338,10 +338,16 @@ def main():
         'speedup_vs_cpu_port': None if cpu is None else round(value / cpu['value'], 1),
         'speedup_vs_rocm_eager': None if not eager or not eager.get('value') else round(value / eager['value'], 1),
     }
-    print(json.dumps(line))
     if distributed:
         gather.close()
         dist.destroy_process_group()
+    # RCCL writes its version banner to C stdout (buffered until exit): flush it first so that the JSON line is the LAST line
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.write(json.dumps(line) + '\n')
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':

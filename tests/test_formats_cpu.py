@@ -59,8 +59,10 @@ def test_kitti_png_encodings(tmp_path):
     assert np.abs(back - flow).max() <= 1 / 64 and (valid == 1).all()
     disp = rs.rand(6, 7).astype(np.float32) * 200
     uio.write_kitti_disp(path, disp)
+    # the reference writer truncates (evaluate_stereo.py:91): exactly those uint16 values must be on disk
+    assert np.array_equal(uio.read_png16(path), (disp * 256.).astype(np.uint16))
     back, valid = uio.read_kitti_disp(path)
-    assert np.abs(back - disp).max() <= 0.5 / 256 + 1e-6 and valid.all()
+    assert (back <= disp + 1e-6).all() and np.abs(back - disp).max() < 1 / 256 + 1e-6 and valid.all()
 
 
 def test_png_reader_handles_all_filter_types(tmp_path):

@@ -373,6 +373,43 @@ def test_end_to_end_exact_mode(name, golden):
         assert (pred - g[f'{name}.fp32']).abs().mean().item() < 1e-3
 
 
+def _parity_tool():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'parity_fullsize.py')
+    spec = importlib.util.spec_from_file_location('parity_fullsize', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
+def test_full_size_parity_absolute_gate(cfg):
+    """The north star's gate -- EPE delta < 1e-3 px against the reference forward on identical inputs -- at the FULL size of
+    every BASELINE.json config (one pair), with the conditioned weight set (``synth.CONDITIONED``: soft softmaxes; the fp32
+    reference port itself agrees with an fp64 evaluation to ~1e-5 px there, so an absolute gate is meaningful).  The GPU
+    output must also stay within 3x of the fp32 port's own distance to fp64.  (tools/parity_fullsize.py prints the whole
+    table incl. random-init weights and thread-order noise: profiles/r02_parity_fullsize.txt.)"""
+    pf = _parity_tool()
+    rec = pf.cpu_legs(cfg, 'conditioned', min(32, __import__('os').cpu_count() or 8), 1, noise=False)
+    got = pf.gpu_leg(cfg, 'conditioned', 'exact')
+    e_gpu, e_port = pf.epe(got, rec['o64']), pf.epe(rec['o32'], rec['o64'])
+    assert e_gpu < 1e-3 and e_gpu <= 3.0 * e_port + 1e-5, (cfg, e_gpu, e_port)
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 5])
+def test_full_size_parity_random_init_noise_floor(cfg):
+    """Random-init weights at full size: the one-scale configs sit on the fp32 noise floor (3e-3 .. 8e-3 px between the
+    fp32 port and fp64); the GPU must be within 1.5x of the port's own error.  The two-scale + refinement configs (3, 4)
+    are chaotic at random init -- the fp32 port is 26 / 71 px from fp64 and 25 / 69 px from ITSELF at another thread count
+    (profiles/r02_parity_fullsize.txt) -- so no comparison means anything there; they are gated with conditioned weights."""
+    pf = _parity_tool()
+    rec = pf.cpu_legs(cfg, 'random', min(32, __import__('os').cpu_count() or 8), 1, noise=False)
+    got = pf.gpu_leg(cfg, 'random', 'exact')
+    e_gpu, e_port = pf.epe(got, rec['o64']), pf.epe(rec['o32'], rec['o64'])
+    assert e_gpu <= 1.5 * e_port + 1e-4, (cfg, e_gpu, e_port)
+
+
 def test_end_to_end_bidirectional_and_batch(golden):
     pred, truth, _ = run_product('gmflow_s1', extra=dict(pred_bidir_flow=True))
     assert pred.shape == (2, 2, 64, 96)

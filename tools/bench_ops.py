@@ -139,7 +139,10 @@ def main():
     if 'gsv' in what:
         B, h, w = 8, 64, 96
         L = h * w
-XX, lambda: ops.global_corr_softmax_flow(f0, f1, h, w),
+        f0, f1 = (torch.randn(B, L, C, device=dev, generator=g) * 3 for _ in range(2))
+        if '--zeros' in args:          # no operand toggling: what the same instruction stream does when it is not power-limited
+            f0, f1 = torch.zeros_like(f0), torch.zeros_like(f1)
+        run('global corr flow cfg2 B=8 L=6144', lambda: ops.global_corr_softmax_flow(f0, f1, h, w),
             B * (2.0 * L * L * C + 4.0 * L * L), lib, iters, 'gsv', issued)
         val = torch.randn(B, 2, h, w, device=dev, generator=g)
         run('global propagation cfg2 B=8 L=6144', lambda: ops.prop_global(f0, f1, val, h, w),

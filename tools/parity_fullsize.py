@@ -59,8 +59,8 @@ def weights(ck, which):
     return synth_state_dict(shapes, **(CONDITIONED if which == 'conditioned' else {}))
 
 
-def cpu_legs(cfg, which, threads, low_threads):
-    """fp64 truth, fp32 port at ``threads`` and at ``low_threads`` (thread-order noise of the reference arithmetic)."""
+def cpu_legs(cfg, which, threads, low_threads, noise=True):
+    """fp64 truth, fp32 port at ``threads`` and (``noise``) at ``low_threads`` (thread-order noise of the reference arithmetic)."""
     path = os.path.join(CACHE, f'cfg{cfg}_{which}.pt')
     if os.path.exists(path):
         return torch.load(path)
@@ -74,10 +74,12 @@ def cpu_legs(cfg, which, threads, low_threads):
     o32 = om.unimatch_forward(sd, i0, i1, **okw)
     t32 = time.time() - t
     o64 = om.unimatch_forward(sd, i0.double(), i1.double(), **to64(okw))
+    rec = {'o64': o64, 'o32': o32, 'threads': threads, 'low_threads': low_threads, 'port_seconds': t32}
+    if not noise:
+        return rec                                   # (not cached: the table wants all three legs)
     torch.set_num_threads(low_threads)
-    o32b = om.unimatch_forward(sd, i0, i1, **okw)
+    rec['o32_low'] = om.unimatch_forward(sd, i0, i1, **okw)
     torch.set_num_threads(threads)
-    rec = {'o64': o64, 'o32': o32, 'o32_low': o32b, 'threads': threads, 'low_threads': low_threads, 'port_seconds': t32}
     os.makedirs(CACHE, exist_ok=True)
     torch.save(rec, path)
     return rec

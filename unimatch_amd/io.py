@@ -18,24 +18,27 @@ FLO_MAGIC = np.array([202021.25], np.float32)
 
 
 class InputPadder:
-    """Pads images such that both dimensions are divisible by ``padding_factor`` (replicate padding).
-    mode 'sintel': symmetric top/bottom; anything else ('kitti'): bottom only.  Same arithmetic as the reference."""
+    """Replicate-pad ``[..., H, W]`` images so that H and W become multiples of ``padding_factor`` and crop predictions back.
+
+    Same interface and the same pad amounts as the reference's helper (utils/utils.py:6-24): the missing rows / columns are
+    ``(-size) mod factor``; ``mode='sintel'`` splits the vertical padding between top and bottom (top gets the smaller half),
+    every other mode (the reference passes 'kitti') puts all of it at the bottom; horizontal padding is always split."""
 
     def __init__(self, dims, mode='sintel', padding_factor=8):
-        self.ht, self.wd = dims[-2:]
-        pad_ht = (((self.ht // padding_factor) + 1) * padding_factor - self.ht) % padding_factor
-        pad_wd = (((self.wd // padding_factor) + 1) * padding_factor - self.wd) % padding_factor
-        if mode == 'sintel':
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
-        else:
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+        height, width = int(dims[-2]), int(dims[-1])
+        extra_h, extra_w = (-height) % padding_factor, (-width) % padding_factor
+        left = extra_w // 2
+        top = extra_h // 2 if mode == 'sintel' else 0
+        # F.pad order: (left, right, top, bottom)
+        self._pad = [left, extra_w - left, top, extra_h - top]
+        self.ht, self.wd = height, width
 
     def pad(self, *inputs):
         return [F.pad(x, self._pad, mode='replicate') for x in inputs]
 
     def unpad(self, x):
-        ht, wd = x.shape[-2:]
-        return x[..., self._pad[2]:ht - self._pad[3], self._pad[0]:wd - self._pad[1]]
+        left, right, top, bottom = self._pad
+        return x[..., top:x.shape[-2] - bottom, left:x.shape[-1] - right]
 
 
 # ------------------------------------------------------------------ Middlebury .flo
@@ -182,7 +185,8 @@ def read_kitti_flow(filename):
 
 
 def write_kitti_disp(filename, disp):
-    write_png16(filename, np.clip(np.round(np.asarray(disp, np.float64) * 256.0), 0, 65535).astype(np.uint16))
+    """disparity * 256 TRUNCATED to uint16, as the reference writer does (evaluate_stereo.py:91: ``(disp * 256.).astype(np.uint16)``)."""
+    write_png16(filename, (np.asarray(disp) * 256.).astype(np.uint16))
 
 
 def read_kitti_disp(filename):

@@ -500,7 +500,7 @@ class UniMatch(nn.Module):
                 assert num_reg_refine > 0
                 pose_r = pose
                 nhwc = None                                     # channels-last refinement block on the library's convolutions
-                if getattr(ops, 'fused_conv', False) and tok0.is_cuda and task in ('flow', 'stereo'):
+                if getattr(ops, 'fused_conv', False) and tok0.is_cuda:      # every task: flow_dim 2 (flow) / 1 (disparity, inverse depth)
                     nhwc = NhwcUpdateBlock(ops, self.refine, self.refine_proj)
                     nhwc.begin(tok0, tok0.shape[0], h, w)
                 else:
