@@ -588,6 +588,422 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gsv4_kernel: ONE wave per SIMD, 64 queries per wave (256 per workgroup), for key counts that are whole 64-key tiles.
+//
+// What the counters said about gsv3_kernel (profiles/r02_pmc_gsv.txt): its pinned inner block is right (4.5 fillers per
+// MFMA), but with two 32-query waves per SIMD the matrix pipe is busy only 70 % of the time a wave is resident -- every
+// wave reads the whole K tile from LDS for 48 MFMAs, the tile-maximum chain and the path selection sit unhidden at the top
+// of each iteration, the last LDS-DMA piece is issued 8 MFMAs before the wait for it -- and the workgroups are resident
+// only 79 % of the launch.  Here
+//   * a wave owns 64 queries = two 32-query blocks: one K fragment read from LDS feeds two MFMAs per product, one tile
+//     costs 96 MFMAs (exact) against 256 softmax VALU + 48 LDS reads + 9 DMA pieces: 3.6 fillers per MFMA, under the ~5 a
+//     lone wave can hide in an MFMA's 32-cycle shadow (MI355X_MICROARCH.md, "one wave per SIMD");
+//   * the Q fragments (128 registers in exact mode) live in the accumulator half of the register file: the MFMAs are issued
+//     through inline asm with the B operand constrained to AGPRs, the score accumulators stay in VGPRs where the softmax
+//     reads them.  hipcc does not see these MFMAs, so the MFMA -> VALU read distance is kept by construction: the softmax
+//     of a tile starts after the third MFMA of the NEXT iteration (plus a workgroup barrier) following the last write;
+//   * no tile maximum on the fast path: the offset Ms only has to keep exp2() finite, so a tile is simply evaluated and
+//     the running sum checked afterwards; if it left (0, 2^90) the lane's state is restored from the pre-tile copy and the
+//     tile redone on the renormalising path (the scores are still in their registers), which also adjusts the pending
+//     accumulators of the next tile.  Exact as before: Ms stays an integer, every rescale is a power of two;
+//   * all LDS-DMA pieces of tile t+2 are issued in the first MFMA gaps of the iteration, a whole tile before their wait.
+// Grid: x = (batch, key split) fastest, so that the 24 query tiles sharing one key range run on one XCD (id % 8).
+template <class T> struct GsvMfmaA;
+template <> struct GsvMfmaA<Fp16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b, const f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+};
+template <> struct GsvMfmaA<Bf16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b, const f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+};
+
+// LDS-DMA with the destination formed in M0 by the same statement (s_add of a wave-uniform base and an immediate); M0 is not
+// saved: hipcc keeps nothing in M0 in this kernel (gfx9 LDS instructions do not need it; checked in the generated .s).
+template <int IMM>
+__device__ __forceinline__ void gsv4_dma16(const void* base, unsigned byte_off, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_base), "i"(IMM) : "memory");
+}
+__device__ __forceinline__ void gsv4_dma4(const void* base, unsigned byte_off, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned gsv4_lds_addr(const unsigned char* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)p);
+}
+
+struct GsvAcc4 {
+    f32x16 a[2][2];          // [32-key sub-tile][32-query block]
+};
+
+#define GSV4_L_LIMIT 1.0e27f        // ~2^90: a running sum outside (0, limit) sends the tile to the renormalising path
+
+template <class T, int NS, int NV>
+__global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
+    constexpr int TK = 64;
+    constexpr int PLANE = TK * 256;
+    constexpr int KSLOT = NS * PLANE;
+    constexpr int VSLOT = NV * TK * 4;
+    constexpr int VBASE = 2 * KSLOT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KSLOT + 4 * VSLOT + 256];   // + a dump row
+    using MF = GsvMfmaA<T>;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int zsplit = blockIdx.x % a.nsplit, b = blockIdx.x / a.nsplit;
+    const int nbatch = gridDim.x / a.nsplit;
+    const int qw = blockIdx.y * 256 + wave * 64 + (lane & 31);          // query of block 0; block 1: + 32
+
+    // ---- Q fragments (B operands), both planes, both query blocks: AGPR residents
+    i16x8 qf[2][NS][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = min(qw + 32 * qb, a.Lq - 1);
+        const unsigned short* qp = a.qp + ((long)b * a.Lq + qr) * UM_CHANNELS + 8 * half;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[qb][pl][ks] = ld_global_16B(qp + pl * a.q_plane_stride + 16 * ks);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[qb][pl][ks]));
+
+    const int ntiles = a.Lk / TK;
+    const int per = (ntiles + a.nsplit - 1) / a.nsplit;
+    const int tbeg = zsplit * per, tend = min(ntiles, tbeg + per);
+    const int n = tend - tbeg;
+
+    // ---- staging: wave w moves rows 16w .. 16w+15 of a tile, 4 rows (64 lanes x 16 B) per DMA instruction; the per-lane
+    // source offsets do not depend on the tile (whole tiles only), the tile enters through the scalar base
+    constexpr int NPIECE = 4 * NS;
+    unsigned koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * wave + (lane >> 4) + 4 * j;
+        koff[j] = (unsigned)(row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+    }
+    const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(a.kp) + (long)b * a.Lk * (UM_CHANNELS * 2);
+    const long kplane_bytes = a.k_plane_stride * 2;
+    const unsigned lds0 = gsv4_lds_addr(lds);
+    const unsigned wrow = lds0 + 16 * wave * 256;                       // this wave's rows of K slot 0
+    // piece i of tile t -> K slot whose LDS address is kslot (+ this wave's row offset)
+    auto k_piece = [&](auto ic, const unsigned char* tile_bytes, unsigned kslot_w) {
+        constexpr int i = decltype(ic)::value, j = i / NS, pl = i % NS;
+        gsv4_dma16<pl * PLANE + 4 * j * 256>(tile_bytes + pl * kplane_bytes, koff[j], kslot_w);
+    };
+    const float* vbase = a.v + (long)b * a.v_batch_stride;
+    // waves 0 .. NV-1 stage one value channel each; the others issue the same instruction into a dump row (no branch:
+    // a branch would split the pinned block)
+    const float* vsrc = vbase + ((wave < NV) ? wave : 0) * a.v_chan_stride;
+    const unsigned vdst0 = (wave < NV) ? lds0 + VBASE + wave * TK * 4 : lds0 + 2 * KSLOT + 4 * VSLOT;
+    const unsigned vstep = (wave < NV) ? VSLOT : 0;
+    auto v_piece = [&](int t, int i) { gsv4_dma4(vsrc, (unsigned)(t * TK + lane) * 4, vdst0 + (i & 3) * vstep); };
+    auto stage_all = [&](int t, int i) {
+        const unsigned char* tb = kbytes + (long)t * (TK * 256);
+        const unsigned kw = wrow + (i & 1) * KSLOT;
+        gsv_static_for(std::make_integer_sequence<int, NPIECE>{}, [&](auto ic) { k_piece(ic, tb, kw); });
+        v_piece(t, i);
+    };
+
+    // ---- running softmax state per (lane, query block): l = sum 2^(score + Ms), acc = sum 2^(score + Ms) v
+    float Ms[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+    float acc[2][NV];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = 0.f;
+    f32x16 cinit[2];          // Ms as the MFMAs' initial accumulator (srcC; must sit in the register half of the destination)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[0][r] = cinit[1][r] = 0.f;
+
+    int kaddr;
+    {
+        const int r = lane & 31, x = r & 15;
+        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
+    }
+    constexpr int NP = (NS == 2) ? 3 : 1;        // products per (k-step, sub-tile, query block)
+    constexpr int MFK = 4 * NP;                  // MFMAs per k-step
+    constexpr int NM = 8 * MFK;                  // MFMAs per tile
+
+    auto frag = [&](const unsigned char* cur, int ridx /* sub * NS + plane */, int ks) {
+        return *reinterpret_cast<const i16x8*>(cur + (ridx / NS) * (32 * 256) + (ridx % NS) * PLANE + (kaddr ^ (ks << 5)));
+    };
+    // MFMA number K of a tile: k-step K / MFK; inside it product-major, then (sub-tile, query block): four different
+    // accumulators in turn, so that no MFMA waits for its predecessor's result
+    auto mfma_step = [&](auto kc, i16x8 (&fr)[2][2 * NS], GsvAcc4& x) {
+        constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK, prod = j / 4, sub = (j >> 1) & 1, qb = j & 1;
+        constexpr int bq = (NS == 2) ? 0 : (ks & 1);
+        constexpr int kpl = (NS == 2 && prod == 0) ? 1 : 0;      // lo_k * hi_q, hi_k * lo_q, hi_k * hi_q
+        constexpr int qpl = (NS == 2 && prod == 1) ? 1 : 0;
+        if constexpr (ks == 0 && prod == 0) MF::init(x.a[sub][qb], fr[bq][sub * NS + kpl], qf[qb][qpl][ks], cinit[qb]);
+        else MF::acc(x.a[sub][qb], fr[bq][sub * NS + kpl], qf[qb][qpl][ks]);
+    };
+    // K fragments of the next k-step.  Exact mode: ONE buffer, every fragment re-read in place right after its last MFMA of
+    // the k-step (lo planes feed product 0 only: free after gaps 1 / 3; hi planes feed products 1 and 2: free after gaps
+    // 9 / 11) -- 16 registers instead of 32, and still 4+ MFMAs between a read and its first use.  Fast mode: two buffers.
+    auto frag_refill = [&](auto kc, const unsigned char* cur, i16x8 (&fr)[2][2 * NS]) {
+        constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK;
+        if constexpr (ks + 1 < 8) {
+            if constexpr (NS == 2) {
+                if constexpr (j == 1) fr[0][1] = frag(cur, 1, ks + 1);
+                if constexpr (j == 3) fr[0][3] = frag(cur, 3, ks + 1);
+                if constexpr (j == 9) fr[0][0] = frag(cur, 0, ks + 1);
+                if constexpr (j == 11) fr[0][2] = frag(cur, 2, ks + 1);
+            } else if constexpr (j < 2) {
+                fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
+            }
+        }
+    };
+    auto mfma_plain = [&](const unsigned char* cur, GsvAcc4& x) {
+        i16x8 fr[2][2 * NS];
+#pragma unroll
+        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
+            mfma_step(kc, fr, x);
+            frag_refill(kc, cur, fr);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // ---- renormalising path for one tile (first tile of a lane, or after the fast path left the safe range)
+    auto slow_update = [&](const GsvAcc4& y, const float* vt, float (&dd)[2]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tm = fmaxf(y.a[0][qb][0], y.a[1][qb][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(y.a[0][qb][r], y.a[1][qb][r]));
+            // the accumulators hold score + Ms.  New offset: the first tile of a lane fixes it; later only upwards.
+            const float d = (l[qb] == 0.f || tm > 0.f) ? ceilf(tm) : 0.f;
+            const float f = (d > 0.f) ? fast_exp2(-d) : 1.f;       // d < 0 only while the state is still empty
+            Ms[qb] -= d;
+            l[qb] *= f;
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) acc[qb][ch] *= f;
+            dd[qb] = d;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 vv[NV];
+#pragma unroll
+                for (int ch = 0; ch < NV; ++ch)
+                    vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + sub * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float p = fast_exp2(y.a[sub][qb][4 * g + i] - dd[qb]);
+                        l[qb] += p;
+#pragma unroll
+                        for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = __builtin_fmaf(p, vv[ch][i], acc[qb][ch]);
+                    }
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[qb][r] = Ms[qb];
+            asm volatile("s_nop 1" : "+v"(cinit[qb]));                    // VALU write -> MFMA srcC wait states, by hand
+        }
+    };
+    // accumulators of the NEXT tile were started from the old offset: move them to the new one
+    auto shift_pending = [&](GsvAcc4& x, const float (&dd)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x.a[sub][qb][r] -= dd[qb];
+    };
+
+    // value group G (4 keys): G >> 2 = sub-tile, G & 3 = register group; shared by both query blocks
+    auto vload = [&](const float* vt, int G, f32x4 (&vv)[NV]) {
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch)
+            vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + (G >> 2) * 32 + 8 * (G & 3) + 4 * half);
+    };
+    // score S of a tile: S >> 3 = value group, (S >> 2) & 1 = query block, S & 3 = key in the group
+    // the exponential is taken one score ahead of its use (a transcendental's result needs a wait state before its consumer)
+    float pn = 0.f;
+    auto score_exp = [&](auto sc, const GsvAcc4& y) {
+        constexpr int S = decltype(sc)::value, G = S >> 3, qb = (S >> 2) & 1, i = S & 3, sub = G >> 2, r = 4 * (G & 3) + i;
+        pn = fast_exp2(y.a[sub][qb][r]);
+    };
+    auto score = [&](auto sc, const GsvAcc4& y, f32x4 (&vv)[2][NV]) {
+        constexpr int S = decltype(sc)::value, G = S >> 3, qb = (S >> 2) & 1, i = S & 3;
+        const float p = pn;
+        if constexpr (S + 1 < 64) {
+            score_exp(std::integral_constant<int, S + 1>{}, y);
+            __builtin_amdgcn_sched_barrier(0);          // the exponential first: three instructions between it and its consumer
+        }
+        l[qb] += p;
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = __builtin_fmaf(p, vv[G & 1][ch][i], acc[qb][ch]);
+    };
+    auto pin_state = [&]() {
+        if constexpr (NV == 2)
+            asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        else
+            asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(acc[0][0]), "+v"(acc[1][0]));
+    };
+
+    // ---- fast path: softmax terms of tile t (accumulators y, read only) in the shadows of the MFMAs of tile t+1 (x).
+    // One basic block; every gap's work is pinned between two scheduling fences.  The first GSV4_HEAD gaps carry no
+    // accumulator reads (hipcc cannot see that the asm MFMAs of the previous iteration wrote y).
+    constexpr int HEAD = 4;
+    auto fused = [&](auto staging_c, const unsigned char* cur, GsvAcc4& x, const GsvAcc4& y, const float* vt, int tnext2,
+                     int inext2) {
+        constexpr bool STAGING = decltype(staging_c)::value;
+        i16x8 fr[2][2 * NS];
+        f32x4 vv[2][NV];
+#pragma unroll
+        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        vload(vt, 0, vv[0]);
+        const unsigned char* tb = kbytes + (long)tnext2 * (TK * 256);
+        const unsigned kw = wrow + (inext2 & 1) * KSLOT;
+        __builtin_amdgcn_sched_barrier(0);
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK;
+            mfma_step(kc, fr, x);
+            frag_refill(kc, cur, fr);
+            if constexpr (STAGING && (K & 1) == 0 && K / 2 <= NPIECE) {       // all DMA of tile t+2 in the first gaps
+                if constexpr (K / 2 < NPIECE) k_piece(std::integral_constant<int, K / 2>{}, tb, kw);
+                else v_piece(tnext2, inext2);
+            }
+            if constexpr (K >= HEAD) {
+                constexpr int NG = NM - HEAD;
+                constexpr int S0 = (K - HEAD) * 64 / NG, S1 = (K - HEAD + 1) * 64 / NG;
+                if constexpr (K == HEAD) score_exp(std::integral_constant<int, 0>{}, y);
+                gsv_static_for(std::make_integer_sequence<int, S1 - S0>{}, [&](auto dc) {
+                    constexpr int S = S0 + decltype(dc)::value;
+                    if constexpr ((S & 7) == 0 && (S >> 3) + 1 < 8) vload(vt, (S >> 3) + 1, vv[((S >> 3) + 1) & 1]);
+                    score(std::integral_constant<int, S>{}, y, vv);
+                });
+                if constexpr (S1 > S0) pin_state();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto tail_update = [&](const GsvAcc4& y, const float* vt) {      // last tile: nothing left to overlap
+        f32x4 vv[2][NV];
+        vload(vt, 0, vv[0]);
+        score_exp(std::integral_constant<int, 0>{}, y);
+        gsv_static_for(std::make_integer_sequence<int, 64>{}, [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if constexpr ((S & 7) == 0 && (S >> 3) + 1 < 8) vload(vt, (S >> 3) + 1, vv[((S >> 3) + 1) & 1]);
+            score(sc, y, vv);
+        });
+    };
+
+    GsvAcc4 xa, xb;
+    if (n > 0) {
+        stage_all(tbeg, 0);
+        if (n > 1) stage_all(tbeg + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_plain(lds, xa);
+    }
+    // iteration i: y = scores of tile i (complete), x = accumulators of tile i+1 (K slot (i+1) & 1)
+    auto iteration = [&](auto par_c, int i, GsvAcc4& y, GsvAcc4& x) {
+        constexpr int NEXT = decltype(par_c)::value ^ 1;               // K slot of tile i+1
+        const int t = tbeg + i;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of tile i+1 has landed
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's; K slot i & 1 is free
+        const float* vt = reinterpret_cast<const float*>(lds + VBASE + (i & 3) * VSLOT);
+        const unsigned char* knext = lds + NEXT * KSLOT;
+        float dd[2];
+        const float l0 = l[0], l1 = l[1];
+        float a0[2][NV];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) a0[qb][ch] = acc[qb][ch];
+        if (i + 2 < n) fused(std::true_type{}, knext, x, y, vt, t + 2, i + 2);
+        else if (i + 1 < n) fused(std::false_type{}, knext, x, y, vt, t + 2, i + 2);
+        else {
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last asm MFMAs of the previous iteration -> VALU
+            __builtin_amdgcn_sched_barrier(0);
+            tail_update(y, vt);
+        }
+        const bool bad = !(l[0] < GSV4_L_LIMIT) || !(l[1] < GSV4_L_LIMIT) || l[0] == 0.f || l[1] == 0.f;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the pending MFMAs' results (asm) -> VALU
+            __builtin_amdgcn_sched_barrier(0);
+            l[0] = l0;
+            l[1] = l1;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = a0[qb][ch];
+            slow_update(y, vt, dd);
+            if (i + 1 < n) shift_pending(x, dd);
+        }
+    };
+    if (n > 0) {                                                        // first tile: fixes the offset (not overlapped)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (n > 2) stage_all(tbeg + 2, 2);
+        if (n > 1) mfma_plain(lds + KSLOT, xb);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float dd[2];
+        slow_update(xa, reinterpret_cast<const float*>(lds + VBASE), dd);
+        if (n > 1) shift_pending(xb, dd);
+    }
+    for (int i = 1; i < n; i += 2) {
+        iteration(std::integral_constant<int, 1>{}, i, xb, xa);
+        if (i + 1 < n) iteration(std::integral_constant<int, 0>{}, i + 1, xa, xb);
+    }
+
+    // ---- merge the two half-waves' partial softmaxes and write (M = Ms: p = 2^(score + M))
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = qw + 32 * qb;
+        const float M = (l[qb] == 0.f) ? 3.0e38f : Ms[qb];
+        const float M2 = __shfl_xor(M, 32);
+        const float l2 = __shfl_xor(l[qb], 32);
+        const float MM = fminf(M, M2);
+        const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
+        const float lt = l[qb] * f1 + l2 * f2;
+        if (a.nsplit > 1) {
+            float* pr = a.partial + (((long)zsplit * nbatch + b) * a.Lq + qi) * (2 + NV);
+            if (half == 0 && qi < a.Lq) {
+                pr[0] = MM;
+                pr[1] = lt;
+            }
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) {
+                const float a2 = __shfl_xor(acc[qb][ch], 32);
+                if (half == 0 && qi < a.Lq) pr[2 + ch] = acc[qb][ch] * f1 + a2 * f2;
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) {
+                const float a2 = __shfl_xor(acc[qb][ch], 32);
+                const float at = acc[qb][ch] * f1 + a2 * f2;
+                if (half == 0 && qi < a.Lq) {
+                    float r = a.alpha * (at / lt);
+                    if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi];
+                    a.out[((long)b * NV + ch) * a.Lq + qi] = r;
+                }
+            }
+        }
+    }
+}
+
 // merge the per-split partial softmaxes: out = alpha * sum_s(acc_s 2^(M-M_s)) / sum_s(l_s 2^(M-M_s)) + beta * v[query]
 template <int NV>
 __global__ void gsv_combine_kernel(GsvArgs a, int nbatch) {
@@ -642,23 +1058,61 @@ static int gsv_choose_split(int qtiles, int nbatch, int ktiles) {
     return best;
 }
 
-// UM_GSV_V2=1 selects round 1's phase-structured kernel (same-box A/B runs); default: the software-pipelined gsv3_kernel,
-// whose operand planes carry sqrt(log2(e) / sqrt(C)) on both sides.
-static bool gsv_use_v2() {
-    static const int v = [] { const char* e = getenv("UM_GSV_V2"); return (e && *e == '1') ? 1 : 0; }();
-    return v != 0;
+// Kernel generation: default gsv4_kernel (one wave per SIMD, 64 queries per wave) wherever the key count is whole 64-key tiles
+// and the launch is not causal, else gsv3_kernel (software-pipelined, two waves per SIMD).  UM_GSV_V3=1 forces gsv3, UM_GSV_V2=1
+// round 1's phase-structured gsv_kernel (same-box A/B runs).  gsv3 / gsv4 operand planes carry sqrt(log2(e) / sqrt(C)) on both sides.
+static int gsv_version() {
+    static const int v = [] {
+        const char* e2 = getenv("UM_GSV_V2");
+        const char* e3 = getenv("UM_GSV_V3");
+        return (e2 && *e2 == '1') ? 2 : ((e3 && *e3 == '1') ? 3 : 4);
+    }();
+    return v;
 }
+static bool gsv_use_v2() { return gsv_version() == 2; }
 static float gsv_plane_scale(float scale_log2) { return gsv_use_v2() ? 1.f : sqrtf(scale_log2); }
+
+// gsv4: one 256-query workgroup per CU.  Key split so that the launch is about three balanced rounds of 256 workgroups.
+static int gsv4_choose_split(int qtiles, int nbatch, int ktiles) {
+    const long wgs = (long)qtiles * nbatch;
+    int best = 1;
+    for (int sp = 1; sp <= GSV_MAX_SPLIT && ktiles / sp >= 8; ++sp) {
+        best = sp;
+        if (wgs * sp >= 768) break;
+    }
+    return best;
+}
 
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
+    const int ver = gsv_version();
+    if (!CAUSAL && ver == 4 && a.Lk % 64 == 0 && a.Lk >= 512) {
+        const int qtiles = (a.Lq + 255) / 256;
+        a.nsplit = partial ? gsv4_choose_split(qtiles, nbatch, a.Lk / 64) : 1;
+        a.partial = partial;
+        dim3 grid(nbatch * a.nsplit, qtiles, 1), block(256);
+        {
+            ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
+            if (mode == 0)
+                hipLaunchKernelGGL((gsv4_kernel<Fp16, 2, NV>), grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL((gsv4_kernel<Bf16, 1, NV>), grid, block, 0, stream, a);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && a.nsplit > 1) {
+            const long total = (long)nbatch * a.Lq;
+            hipLaunchKernelGGL((gsv_combine_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, nbatch);
+            e = hipGetLastError();
+        }
+        return e;
+    }
     const int qtiles = (a.Lq + 127) / 128;
     a.nsplit = (CAUSAL || !partial) ? 1 : gsv_choose_split(qtiles, nbatch, (a.Lk + 63) / 64);
     a.partial = partial;
     dim3 grid(qtiles, nbatch, a.nsplit), block(256);
     {
         ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
-        if (gsv_use_v2()) {
+        if (ver == 2) {
             if (mode == 0)
                 hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
             else
