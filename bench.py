@@ -22,7 +22,7 @@ Extra objects on the line:
                         (two event records per timed launch: the headline is slightly pessimistic), against the dense 16-bit
                         MFMA peak; ``traffic`` comes from a rocprofv3 PMC pass kept in profiles/ and is nulled when the
                         kernel source has changed since that pass.
-  roofline_global_corr  the same for ``gsv_kernel`` (the kernel the north star names).
+  roofline_global_corr  the same for ``gsv4_kernel`` (global correlation / propagation: the kernel the north star names).
   fast                  the bf16 throughput mode of the same workload (pairs/s, both rooflines, EPE vs fp64): reported beside
                         the headline, never as the headline and never as a parity claim.
   cpu_baseline          the CPU port (oracle/, a torch-CPU restatement of the reference pinned to it by golden fixtures;
@@ -100,7 +100,7 @@ def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch):
     out = []
     for name, key, files, (ms, n), fl in (
             ('window_attn_kernel', f'window_attn_kernel<{tag}, true>', ['window_attn.hip', 'common.h'], attn, flops_attn),
-            ('gsv_kernel (global correlation / propagation)', f'gsv_kernel<{tag}, 2, false>', ['global_match.hip', 'common.h'],
+            ('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
              gsv, flops_gsv)):
         if not n:
             out.append(None)

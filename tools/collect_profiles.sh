@@ -20,11 +20,11 @@ if [ -n "$TRACE" ]; then python tools/steady_state.py "$TRACE" 10 > "$OUT/${TAG}
 (cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/${TAG}_pmc -o p -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmc.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmc -name '*counter_collection.csv' | head -1)
-if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply window_attn gsv_kernel ffn_kernel linear_kernel > "$OUT/${TAG}_pmc_fetch.json"; fi
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply window_attn gsv ffn_kernel linear_kernel > "$OUT/${TAG}_pmc_fetch.json"; fi
 (cd /tmp && timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/${TAG}_pmcw -o p -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcw.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmcw -name '*counter_collection.csv' | head -1)
-if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv_kernel > "$OUT/${TAG}_pmc_write.json"; fi
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv > "$OUT/${TAG}_pmc_write.json"; fi
 # then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json
 timeout 150 python tools/bench_configs.py --steps 10 2>&1 | grep cfg > "$OUT/${TAG}_all_configs.txt"
 (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_cfg4" -o p -- \

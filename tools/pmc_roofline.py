@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import PMC_FILE, source_stamp  # noqa: E402
 
-KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv_kernel': ['global_match.hip', 'common.h']}
+KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv_kernel': ['global_match.hip', 'common.h'],
+           'gsv3_kernel': ['global_match.hip', 'common.h'], 'gsv4_kernel': ['global_match.hip', 'common.h']}
 
 
 def main():

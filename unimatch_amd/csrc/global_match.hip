@@ -35,6 +35,9 @@ struct GsvArgs {
     float alpha, beta;
     int nsplit;                 // key range split across gridDim.z workgroups (load balance); 1 = direct output
     float* partial;             // nsplit > 1: [nsplit][nbatch][Lq][2 + NV] = (M, l, acc...) per split
+    // gsv4_kernel ("stream-K" decomposition): the (batch, 256-query tile, 64-key tile) units, key tile fastest, are cut into
+    // equal chunks, one per workgroup; a query tile's segments go to partial slots 0, 1, ... in chunk order
+    int nbatch, qtiles, chunk;
 };
 
 // 16 (or 4) bytes per lane, global -> LDS without passing through VGPRs (LDS address = wave-uniform dst + size * lane).
@@ -631,7 +634,7 @@ template <> struct GsvMfmaA<Bf16> {
 // saved: hipcc keeps nothing in M0 in this kernel (gfx9 LDS instructions do not need it; checked in the generated .s).
 template <int IMM>
 __device__ __forceinline__ void gsv4_dma16(const void* base, unsigned byte_off, unsigned lds_base) {
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_base), "i"(IMM) : "memory");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_base), "i"(IMM) : "memory", "scc");
 }
 __device__ __forceinline__ void gsv4_dma4(const void* base, unsigned byte_off, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
@@ -651,17 +654,47 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
     constexpr int TK = 64;
     constexpr int PLANE = TK * 256;
     constexpr int KSLOT = NS * PLANE;
+    constexpr int NKSLOT = 3;
     constexpr int VSLOT = NV * TK * 4;
-    constexpr int VBASE = 2 * KSLOT;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KSLOT + 4 * VSLOT + 256];   // + a dump row
+    constexpr int VBASE = NKSLOT * KSLOT;
+    constexpr int DUMP = VBASE + 4 * VSLOT;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DUMP + 256];   // 3 K slots, 4 value slots, a dump row
     using MF = GsvMfmaA<T>;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int zsplit = blockIdx.x % a.nsplit, b = blockIdx.x / a.nsplit;
-    const int nbatch = gridDim.x / a.nsplit;
-    const int qw = blockIdx.y * 256 + wave * 64 + (lane & 31);          // query of block 0; block 1: + 32
+    // ---- this workgroup's chunk of (batch, query tile, key tile) units; XCD-aware: consecutive chunks (same batch, same
+    // keys) go to the workgroups of one XCD
+    const int KT = a.Lk / TK;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const long ubeg = (long)wg * a.chunk;
+    const long uend = min((long)a.nbatch * a.qtiles * KT, ubeg + a.chunk);
+    constexpr int NPIECE = 4 * NS;
+    unsigned koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * wave + (lane >> 4) + 4 * j;
+        koff[j] = (unsigned)(row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+    }
+    const long kplane_bytes = a.k_plane_stride * 2;
+    const unsigned lds0 = gsv4_lds_addr(lds);
+    const unsigned wrow = lds0 + 16 * wave * 256;                       // this wave's rows of K slot 0
+    int kaddr;
+    {
+        const int r = lane & 31, x = r & 15;
+        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
+    }
+
+  for (long u = ubeg; u < uend;) {                                      // one segment = this chunk's part of one query tile
+    const int qtile = (int)(u / KT);
+    const int tbeg = (int)(u - (long)qtile * KT);
+    const int n = (int)min((long)(KT - tbeg), uend - u);
+    const int b = qtile / a.qtiles;
+    const int slot = wg - (int)(((long)qtile * KT) / a.chunk);         // this segment's partial slot
+    const int qw = (qtile - b * a.qtiles) * 256 + wave * 64 + (lane & 31);   // query of block 0; block 1: + 32
+    u += n;
+    __builtin_amdgcn_s_barrier();                                       // the previous segment is out of the LDS
 
     // ---- Q fragments (B operands), both planes, both query blocks: AGPR residents
     i16x8 qf[2][NS][8];
@@ -681,26 +714,11 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[qb][pl][ks]));
 
-    const int ntiles = a.Lk / TK;
-    const int per = (ntiles + a.nsplit - 1) / a.nsplit;
-    const int tbeg = zsplit * per, tend = min(ntiles, tbeg + per);
-    const int n = tend - tbeg;
-
     // ---- staging: wave w moves rows 16w .. 16w+15 of a tile, 4 rows (64 lanes x 16 B) per DMA instruction; the per-lane
     // source offsets do not depend on the tile (whole tiles only), the tile enters through the scalar base
-    constexpr int NPIECE = 4 * NS;
-    unsigned koff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 16 * wave + (lane >> 4) + 4 * j;
-        koff[j] = (unsigned)(row * 256 + (((lane & 15) ^ (row & 15)) << 4));
-    }
     const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(a.kp) + (long)b * a.Lk * (UM_CHANNELS * 2);
-    const long kplane_bytes = a.k_plane_stride * 2;
-    const unsigned lds0 = gsv4_lds_addr(lds);
-    const unsigned wrow = lds0 + 16 * wave * 256;                       // this wave's rows of K slot 0
-    // piece i of tile t -> K slot whose LDS address is kslot (+ this wave's row offset)
-    auto k_piece = [&](auto ic, const unsigned char* tile_bytes, unsigned kslot_w) {
+    // piece i of the tile at tile_bytes -> the K slot whose LDS address (+ this wave's row offset) is kslot_w
+    auto k_piece = [&](auto ic, const unsigned char* tile_bytes, unsigned kslot_w) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, j = i / NS, pl = i % NS;
         gsv4_dma16<pl * PLANE + 4 * j * 256>(tile_bytes + pl * kplane_bytes, koff[j], kslot_w);
     };
@@ -708,13 +726,13 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
     // waves 0 .. NV-1 stage one value channel each; the others issue the same instruction into a dump row (no branch:
     // a branch would split the pinned block)
     const float* vsrc = vbase + ((wave < NV) ? wave : 0) * a.v_chan_stride;
-    const unsigned vdst0 = (wave < NV) ? lds0 + VBASE + wave * TK * 4 : lds0 + 2 * KSLOT + 4 * VSLOT;
+    const unsigned vdst0 = (wave < NV) ? lds0 + VBASE + wave * TK * 4 : lds0 + DUMP;
     const unsigned vstep = (wave < NV) ? VSLOT : 0;
-    auto v_piece = [&](int t, int i) { gsv4_dma4(vsrc, (unsigned)(t * TK + lane) * 4, vdst0 + (i & 3) * vstep); };
-    auto stage_all = [&](int t, int i) {
+    auto v_piece = [&](int t, int i) __attribute__((always_inline)) { gsv4_dma4(vsrc, (unsigned)(t * TK + lane) * 4, vdst0 + (i & 3) * vstep); };
+    auto stage_all = [&](int t, int i, int kslot) __attribute__((always_inline)) {
         const unsigned char* tb = kbytes + (long)t * (TK * 256);
-        const unsigned kw = wrow + (i & 1) * KSLOT;
-        gsv_static_for(std::make_integer_sequence<int, NPIECE>{}, [&](auto ic) { k_piece(ic, tb, kw); });
+        const unsigned kw = wrow + kslot * KSLOT;
+        gsv_static_for(std::make_integer_sequence<int, NPIECE>{}, [&](auto ic) __attribute__((always_inline)) { k_piece(ic, tb, kw); });
         v_piece(t, i);
     };
 
@@ -729,21 +747,19 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[0][r] = cinit[1][r] = 0.f;
 
-    int kaddr;
-    {
-        const int r = lane & 31, x = r & 15;
-        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
-    }
     constexpr int NP = (NS == 2) ? 3 : 1;        // products per (k-step, sub-tile, query block)
     constexpr int MFK = 4 * NP;                  // MFMAs per k-step
     constexpr int NM = 8 * MFK;                  // MFMAs per tile
+    constexpr int HEAD = 4;                      // leading gaps of a block without accumulator reads (see header)
+    constexpr int MID = NM / 2;                  // the block's workgroup barrier sits in front of MFMA number MID
 
-    auto frag = [&](const unsigned char* cur, int ridx /* sub * NS + plane */, int ks) {
-        return *reinterpret_cast<const i16x8*>(cur + (ridx / NS) * (32 * 256) + (ridx % NS) * PLANE + (kaddr ^ (ks << 5)));
+    // fragment of the K slot whose per-lane base is kb = kaddr + slot * KSLOT
+    auto frag = [&](int kb, int ridx /* sub * NS + plane */, int ks) __attribute__((always_inline)) {
+        return *reinterpret_cast<const i16x8*>(lds + (ridx / NS) * (32 * 256) + (ridx % NS) * PLANE + (kb ^ (ks << 5)));
     };
     // MFMA number K of a tile: k-step K / MFK; inside it product-major, then (sub-tile, query block): four different
     // accumulators in turn, so that no MFMA waits for its predecessor's result
-    auto mfma_step = [&](auto kc, i16x8 (&fr)[2][2 * NS], GsvAcc4& x) {
+    auto mfma_step = [&](auto kc, i16x8 (&fr)[2][2 * NS], GsvAcc4& x) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK, prod = j / 4, sub = (j >> 1) & 1, qb = j & 1;
         constexpr int bq = (NS == 2) ? 0 : (ks & 1);
         constexpr int kpl = (NS == 2 && prod == 0) ? 1 : 0;      // lo_k * hi_q, hi_k * lo_q, hi_k * hi_q
@@ -751,35 +767,37 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         if constexpr (ks == 0 && prod == 0) MF::init(x.a[sub][qb], fr[bq][sub * NS + kpl], qf[qb][qpl][ks], cinit[qb]);
         else MF::acc(x.a[sub][qb], fr[bq][sub * NS + kpl], qf[qb][qpl][ks]);
     };
-    // K fragments of the next k-step.  Exact mode: ONE buffer, every fragment re-read in place right after its last MFMA of
-    // the k-step (lo planes feed product 0 only: free after gaps 1 / 3; hi planes feed products 1 and 2: free after gaps
-    // 9 / 11) -- 16 registers instead of 32, and still 4+ MFMAs between a read and its first use.  Fast mode: two buffers.
-    auto frag_refill = [&](auto kc, const unsigned char* cur, i16x8 (&fr)[2][2 * NS]) {
-        constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK;
-        if constexpr (ks + 1 < 8) {
-            if constexpr (NS == 2) {
-                if constexpr (j == 1) fr[0][1] = frag(cur, 1, ks + 1);
-                if constexpr (j == 3) fr[0][3] = frag(cur, 3, ks + 1);
-                if constexpr (j == 9) fr[0][0] = frag(cur, 0, ks + 1);
-                if constexpr (j == 11) fr[0][2] = frag(cur, 2, ks + 1);
-            } else if constexpr (j < 2) {
-                fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
-            }
+    // K fragments of the next k-step -- after the last k-step: the FIRST k-step of the next tile (slot base kb_next), so
+    // that a block starts with its operands in registers.  Exact mode: ONE buffer, every fragment re-read in place right
+    // after its last MFMA of the k-step (lo planes feed product 0 only: free after gaps 1 / 3; hi planes feed products 1
+    // and 2: free after gaps 9 / 11) -- 16 registers instead of 32, and still 4+ MFMAs between a read and its first use.
+    // Fast mode: two buffers.
+    auto frag_refill = [&](auto kc, int kb, int kb_next, i16x8 (&fr)[2][2 * NS]) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK, nk = (ks + 1) & 7;
+        const int src = (ks + 1 < 8) ? kb : kb_next;
+        if constexpr (NS == 2) {
+            if constexpr (j == 1) fr[0][1] = frag(src, 1, nk);
+            if constexpr (j == 3) fr[0][3] = frag(src, 3, nk);
+            if constexpr (j == 9) fr[0][0] = frag(src, 0, nk);
+            if constexpr (j == 11) fr[0][2] = frag(src, 2, nk);
+        } else if constexpr (j < 2) {
+            fr[nk & 1][j] = frag(src, j, nk);
         }
     };
-    auto mfma_plain = [&](const unsigned char* cur, GsvAcc4& x) {
-        i16x8 fr[2][2 * NS];
+    auto frag_first = [&](int kb, i16x8 (&fr)[2][2 * NS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
-        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
+        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(kb, ri, 0);
+    };
+    auto mfma_plain = [&](int kb, int kb_next, i16x8 (&fr)[2][2 * NS], GsvAcc4& x) __attribute__((always_inline)) {
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) __attribute__((always_inline)) {
             mfma_step(kc, fr, x);
-            frag_refill(kc, cur, fr);
+            frag_refill(kc, kb, kb_next, fr);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
 
     // ---- renormalising path for one tile (first tile of a lane, or after the fast path left the safe range)
-    auto slow_update = [&](const GsvAcc4& y, const float* vt, float (&dd)[2]) {
+    auto slow_update = [&](const GsvAcc4& y, const float* vt, float (&dd)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float tm = fmaxf(y.a[0][qb][0], y.a[1][qb][0]);
@@ -820,7 +838,7 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         }
     };
     // accumulators of the NEXT tile were started from the old offset: move them to the new one
-    auto shift_pending = [&](GsvAcc4& x, const float (&dd)[2]) {
+    auto shift_pending = [&](GsvAcc4& x, const float (&dd)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -830,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
     };
 
     // value group G (4 keys): G >> 2 = sub-tile, G & 3 = register group; shared by both query blocks
-    auto vload = [&](const float* vt, int G, f32x4 (&vv)[NV]) {
+    auto vload = [&](const float* vt, int G, f32x4 (&vv)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ch = 0; ch < NV; ++ch)
             vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + (G >> 2) * 32 + 8 * (G & 3) + 4 * half);
@@ -838,11 +856,11 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
     // score S of a tile: S >> 3 = value group, (S >> 2) & 1 = query block, S & 3 = key in the group
     // the exponential is taken one score ahead of its use (a transcendental's result needs a wait state before its consumer)
     float pn = 0.f;
-    auto score_exp = [&](auto sc, const GsvAcc4& y) {
+    auto score_exp = [&](auto sc, const GsvAcc4& y) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value, G = S >> 3, qb = (S >> 2) & 1, i = S & 3, sub = G >> 2, r = 4 * (G & 3) + i;
         pn = fast_exp2(y.a[sub][qb][r]);
     };
-    auto score = [&](auto sc, const GsvAcc4& y, f32x4 (&vv)[2][NV]) {
+    auto score = [&](auto sc, const GsvAcc4& y, f32x4 (&vv)[2][NV]) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value, G = S >> 3, qb = (S >> 2) & 1, i = S & 3;
         const float p = pn;
         if constexpr (S + 1 < 64) {
@@ -853,93 +871,141 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
 #pragma unroll
         for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = __builtin_fmaf(p, vv[G & 1][ch][i], acc[qb][ch]);
     };
-    auto pin_state = [&]() {
+    auto pin_state = [&]() __attribute__((always_inline)) {
         if constexpr (NV == 2)
             asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         else
             asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(acc[0][0]), "+v"(acc[1][0]));
     };
 
-    // ---- fast path: softmax terms of tile t (accumulators y, read only) in the shadows of the MFMAs of tile t+1 (x).
-    // One basic block; every gap's work is pinned between two scheduling fences.  The first GSV4_HEAD gaps carry no
-    // accumulator reads (hipcc cannot see that the asm MFMAs of the previous iteration wrote y).
-    constexpr int HEAD = 4;
-    auto fused = [&](auto staging_c, const unsigned char* cur, GsvAcc4& x, const GsvAcc4& y, const float* vt, int tnext2,
-                     int inext2) {
-        constexpr bool STAGING = decltype(staging_c)::value;
-        i16x8 fr[2][2 * NS];
-        f32x4 vv[2][NV];
-#pragma unroll
-        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
-        vload(vt, 0, vv[0]);
-        const unsigned char* tb = kbytes + (long)tnext2 * (TK * 256);
-        const unsigned kw = wrow + (inext2 & 1) * KSLOT;
-        __builtin_amdgcn_sched_barrier(0);
-        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
-            constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK;
-            mfma_step(kc, fr, x);
-            frag_refill(kc, cur, fr);
-            if constexpr (STAGING && (K & 1) == 0 && K / 2 <= NPIECE) {       // all DMA of tile t+2 in the first gaps
-                if constexpr (K / 2 < NPIECE) k_piece(std::integral_constant<int, K / 2>{}, tb, kw);
-                else v_piece(tnext2, inext2);
+    // ---- the schedule of one block: which fillers sit in the shadow of MFMA number K.
+    // Exact mode, per k-step of 12 MFMAs: gaps 1, 3, 9, 11 carry the fragment refills (+ the value loads at gap 3, + one
+    // DMA piece at gaps 1 / 9 / 11 of k-steps 4 - 6, after the barrier), the other eight gaps one score each (exp, add, two
+    // fma); the first block gaps read no accumulator; the two scores this leaves over go to gaps 9 / 11 of the last k-step.
+    // Fast mode (4 MFMAs per k-step): scores spread evenly, DMA in the odd gaps after the barrier.
+    struct Sched {
+        static constexpr bool refill_gap(int j) { return j == 1 || j == 3 || j == 9 || j == 11; }
+        static constexpr int scores_in(int K) {          // scores issued in gap K
+            if (K < HEAD) return 0;
+            if (NS == 2) {
+                const int ks = K / MFK, j = K % MFK;
+                if (!refill_gap(j)) return 1;
+                return (ks == 7 && (j == 9 || j == 11)) ? 1 : 0;
             }
-            if constexpr (K >= HEAD) {
-                constexpr int NG = NM - HEAD;
-                constexpr int S0 = (K - HEAD) * 64 / NG, S1 = (K - HEAD + 1) * 64 / NG;
-                if constexpr (K == HEAD) score_exp(std::integral_constant<int, 0>{}, y);
-                gsv_static_for(std::make_integer_sequence<int, S1 - S0>{}, [&](auto dc) {
+            return (K - HEAD + 1) * 64 / (NM - HEAD) - (K - HEAD) * 64 / (NM - HEAD);
+        }
+        static constexpr int scores_before(int K) {
+            int c = 0;
+            for (int k = 0; k < K; ++k) c += scores_in(k);
+            return c;
+        }
+        static constexpr int dma_piece(int K) {          // -1: none; 0 .. NPIECE-1: K piece; NPIECE: the value piece
+            if (K <= MID) return -1;
+            if (NS == 2) {
+                const int ks = K / MFK, j = K % MFK;
+                if (ks < 4 || ks > 6) return -1;
+                const int slot = (j == 1) ? 0 : (j == 9) ? 1 : (j == 11) ? 2 : -1;
+                return slot < 0 ? -1 : (ks - 4) * 3 + slot;
+            }
+            const int d = K - MID;
+            return ((d & 1) && d / 2 <= NPIECE) ? d / 2 : -1;
+        }
+    };
+    static_assert(Sched::scores_before(NM) == 64, "every score of a tile must be scheduled");
+
+    // ---- fast path: softmax terms of tile i (accumulators y, read only) in the shadows of the MFMAs of tile i+1 (x).
+    // One basic block; every gap's work is pinned between two scheduling fences.  In front of MFMA number MID: this wave's
+    // DMA of tile i+2 has landed (vmcnt) and a workgroup barrier -- after it tile i+2 is visible to everybody AND everybody
+    // has finished block i-1, so the K slot of tile i (= slot of tile i+3) and the value slot of tile i-1 may be refilled.
+    auto fused = [&](auto staging_c, int kb, int kb_next, i16x8 (&fr)[2][2 * NS], GsvAcc4& x, const GsvAcc4& y, const float* vt,
+                     int t3, int i3, int kslot3) __attribute__((always_inline)) {
+        constexpr bool STAGING = decltype(staging_c)::value;
+        f32x4 vv[2][NV];
+        vload(vt, 0, vv[0]);
+        const unsigned char* tb = kbytes + (long)t3 * (TK * 256);
+        const unsigned kw = wrow + kslot3 * KSLOT;
+        __builtin_amdgcn_sched_barrier(0);
+        gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value, ks = K / MFK, j = K % MFK;
+            if constexpr (K == MID) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_step(kc, fr, x);
+            frag_refill(kc, kb, kb_next, fr);
+            if constexpr (STAGING && Sched::dma_piece(K) >= 0) {
+                constexpr int pc = Sched::dma_piece(K);
+                if constexpr (pc < NPIECE) k_piece(std::integral_constant<int, pc>{}, tb, kw);
+                else v_piece(t3, i3);
+            }
+            if constexpr (NS == 2 && j == 3 && ks + 1 < 8) vload(vt, ks + 1, vv[(ks + 1) & 1]);
+            constexpr int S0 = Sched::scores_before(K), NSC = Sched::scores_in(K);
+            if constexpr (NSC > 0) {
+                if constexpr (S0 == 0) score_exp(std::integral_constant<int, 0>{}, y);
+                gsv_static_for(std::make_integer_sequence<int, NSC>{}, [&](auto dc) __attribute__((always_inline)) {
                     constexpr int S = S0 + decltype(dc)::value;
-                    if constexpr ((S & 7) == 0 && (S >> 3) + 1 < 8) vload(vt, (S >> 3) + 1, vv[((S >> 3) + 1) & 1]);
+                    if constexpr (NS == 1 && (S & 7) == 0 && (S >> 3) + 1 < 8) vload(vt, (S >> 3) + 1, vv[((S >> 3) + 1) & 1]);
                     score(std::integral_constant<int, S>{}, y, vv);
                 });
-                if constexpr (S1 > S0) pin_state();
+                pin_state();
             }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto tail_update = [&](const GsvAcc4& y, const float* vt) {      // last tile: nothing left to overlap
+    auto tail_update = [&](const GsvAcc4& y, const float* vt) __attribute__((always_inline)) {      // last tile: nothing left to overlap
         f32x4 vv[2][NV];
         vload(vt, 0, vv[0]);
         score_exp(std::integral_constant<int, 0>{}, y);
-        gsv_static_for(std::make_integer_sequence<int, 64>{}, [&](auto sc) {
+        gsv_static_for(std::make_integer_sequence<int, 64>{}, [&](auto sc) __attribute__((always_inline)) {
             constexpr int S = decltype(sc)::value;
             if constexpr ((S & 7) == 0 && (S >> 3) + 1 < 8) vload(vt, (S >> 3) + 1, vv[((S >> 3) + 1) & 1]);
             score(sc, y, vv);
         });
     };
 
+    // ---- pipeline.  Tile with local index i: K slot i % 3, value slot i & 3, accumulators xa (i even) / xb (i odd).
+    // Block i (i >= 1): softmax of tile i, MFMAs of tile i+1, DMA of tile i+3, first fragments of tile i+2.
     GsvAcc4 xa, xb;
-    if (n > 0) {
-        stage_all(tbeg, 0);
-        if (n > 1) stage_all(tbeg + 1, 1);
+    i16x8 fr[2][2 * NS];
+    {
+        stage_all(tbeg, 0, 0);
+        if (n > 1) stage_all(tbeg + 1, 1, 1);
+        if (n > 2) stage_all(tbeg + 2, 2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mfma_plain(lds, xa);
-    }
-    // iteration i: y = scores of tile i (complete), x = accumulators of tile i+1 (K slot (i+1) & 1)
-    auto iteration = [&](auto par_c, int i, GsvAcc4& y, GsvAcc4& x) {
-        constexpr int NEXT = decltype(par_c)::value ^ 1;               // K slot of tile i+1
-        const int t = tbeg + i;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of tile i+1 has landed
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's; K slot i & 1 is free
-        const float* vt = reinterpret_cast<const float*>(lds + VBASE + (i & 3) * VSLOT);
-        const unsigned char* knext = lds + NEXT * KSLOT;
+        // tile 0 alone, then block 0: the first tile fixes the offset (not overlapped)
+        frag_first(kaddr, fr);
+        mfma_plain(kaddr, kaddr + KSLOT, fr, xa);
+        __builtin_amdgcn_s_barrier();                                   // K slot 0 is free
+        if (n > 3) stage_all(tbeg + 3, 3, 0);
+        if (n > 1) mfma_plain(kaddr + KSLOT, kaddr + 2 * KSLOT, fr, xb);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         float dd[2];
+        slow_update(xa, reinterpret_cast<const float*>(lds + VBASE), dd);
+        if (n > 1) shift_pending(xb, dd);
+    }
+    int s1 = 2, s2 = 0, s3 = 1;                                         // K slots of tiles i+1, i+2, i+3 at i = 1
+    auto iteration = [&](int i, GsvAcc4& y, GsvAcc4& x) __attribute__((always_inline)) {
+        const float* vt = reinterpret_cast<const float*>(lds + VBASE + (i & 3) * VSLOT);
+        const int kb = kaddr + s1 * KSLOT, kb_next = kaddr + s2 * KSLOT;
         const float l0 = l[0], l1 = l[1];
         float a0[2][NV];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int ch = 0; ch < NV; ++ch) a0[qb][ch] = acc[qb][ch];
-        if (i + 2 < n) fused(std::true_type{}, knext, x, y, vt, t + 2, i + 2);
-        else if (i + 1 < n) fused(std::false_type{}, knext, x, y, vt, t + 2, i + 2);
+        if (i + 3 < n) fused(std::true_type{}, kb, kb_next, fr, x, y, vt, tbeg + i + 3, i + 3, s3);
+        else if (i + 1 < n) fused(std::false_type{}, kb, kb_next, fr, x, y, vt, tbeg + i + 3, i + 3, s3);
         else {
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last asm MFMAs of the previous iteration -> VALU
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // last asm MFMAs of the previous block -> VALU
             __builtin_amdgcn_sched_barrier(0);
             tail_update(y, vt);
         }
         const bool bad = !(l[0] < GSV4_L_LIMIT) || !(l[1] < GSV4_L_LIMIT) || l[0] == 0.f || l[1] == 0.f;
         if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+            float dd[2];
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the pending MFMAs' results (asm) -> VALU
             __builtin_amdgcn_sched_barrier(0);
             l[0] = l0;
@@ -951,22 +1017,16 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
             slow_update(y, vt, dd);
             if (i + 1 < n) shift_pending(x, dd);
         }
+        const int s0 = s1;
+        s1 = s2;
+        s2 = s3;
+        s3 = s0;
     };
-    if (n > 0) {                                                        // first tile: fixes the offset (not overlapped)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (n > 2) stage_all(tbeg + 2, 2);
-        if (n > 1) mfma_plain(lds + KSLOT, xb);
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        float dd[2];
-        slow_update(xa, reinterpret_cast<const float*>(lds + VBASE), dd);
-        if (n > 1) shift_pending(xb, dd);
-    }
     for (int i = 1; i < n; i += 2) {
-        iteration(std::integral_constant<int, 1>{}, i, xb, xa);
-        if (i + 1 < n) iteration(std::integral_constant<int, 0>{}, i + 1, xa, xb);
+        iteration(i, xb, xa);
+        if (i + 1 < n) iteration(i + 1, xa, xb);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- merge the two half-waves' partial softmaxes and write (M = Ms: p = 2^(score + M))
 #pragma unroll
@@ -978,8 +1038,8 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         const float MM = fminf(M, M2);
         const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
         const float lt = l[qb] * f1 + l2 * f2;
-        if (a.nsplit > 1) {
-            float* pr = a.partial + (((long)zsplit * nbatch + b) * a.Lq + qi) * (2 + NV);
+        if (a.partial) {
+            float* pr = a.partial + (((long)slot * a.nbatch + b) * a.Lq + qi) * (2 + NV);
             if (half == 0 && qi < a.Lq) {
                 pr[0] = MM;
                 pr[1] = lt;
@@ -1001,6 +1061,38 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
                 }
             }
         }
+    }
+  }   // segments
+}
+
+// merge a query's segments (gsv4_kernel): its tile's units [qtile * KT, (qtile + 1) * KT) lie in chunks w0 .. w1 = slots 0 .. w1 - w0
+template <int NV>
+__global__ void gsv4_combine_kernel(GsvArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.nbatch * a.Lq;
+    if (i >= total) return;
+    const int b = (int)(i / a.Lq), q = (int)(i - (long)b * a.Lq);
+    const int KT = a.Lk / 64;
+    const long qtile = (long)b * a.qtiles + q / 256;
+    const int nseg = (int)(((qtile + 1) * KT - 1) / a.chunk - (qtile * KT) / a.chunk) + 1;
+    float MM = 3.0e38f;
+    for (int sp = 0; sp < nseg; ++sp) MM = fminf(MM, a.partial[((long)sp * total + i) * (2 + NV)]);
+    float lt = 0.f, at[NV];
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) at[ch] = 0.f;
+    for (int sp = 0; sp < nseg; ++sp) {
+        const float* pr = a.partial + ((long)sp * total + i) * (2 + NV);
+        const float f = fast_exp2(MM - pr[0]);
+        lt += pr[1] * f;
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) at[ch] += pr[2 + ch] * f;
+    }
+    const float* vbase = a.v + (long)b * a.v_batch_stride;
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) {
+        float r = a.alpha * (at[ch] / lt);
+        if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + q];
+        a.out[((long)b * NV + ch) * a.Lq + q] = r;
     }
 }
 
@@ -1072,36 +1164,47 @@ static int gsv_version() {
 static bool gsv_use_v2() { return gsv_version() == 2; }
 static float gsv_plane_scale(float scale_log2) { return gsv_use_v2() ? 1.f : sqrtf(scale_log2); }
 
-// gsv4: one 256-query workgroup per CU.  Key split so that the launch is about three balanced rounds of 256 workgroups.
-static int gsv4_choose_split(int qtiles, int nbatch, int ktiles) {
-    const long wgs = (long)qtiles * nbatch;
-    int best = 1;
-    for (int sp = 1; sp <= GSV_MAX_SPLIT && ktiles / sp >= 8; ++sp) {
-        best = sp;
-        if (wgs * sp >= 768) break;
-    }
-    return best;
+// gsv4: one workgroup per CU, all of them resident at once ("stream-K"): the (batch, 256-query tile, 64-key tile) units are cut
+// into equal chunks.  A chunk is at least 8 key tiles and a query tile is cut into at most GSV_MAX_SPLIT segments.
+static int gsv_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
 }
 
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
     const int ver = gsv_version();
     if (!CAUSAL && ver == 4 && a.Lk % 64 == 0 && a.Lk >= 512) {
-        const int qtiles = (a.Lq + 255) / 256;
-        a.nsplit = partial ? gsv4_choose_split(qtiles, nbatch, a.Lk / 64) : 1;
-        a.partial = partial;
-        dim3 grid(nbatch * a.nsplit, qtiles, 1), block(256);
+        const int KT = a.Lk / 64;
+        a.nbatch = nbatch;
+        a.qtiles = (a.Lq + 255) / 256;
+        const long units = (long)nbatch * a.qtiles * KT;
+        long chunk = (units + gsv_num_cus() - 1) / gsv_num_cus();
+        const long min_chunk = (KT + GSV_MAX_SPLIT - 3) / (GSV_MAX_SPLIT - 2);     // at most GSV_MAX_SPLIT segments per query tile
+        if (chunk < min_chunk) chunk = min_chunk;
+        if (chunk < 8) chunk = 8;
+        if (!partial || chunk > KT) chunk = ((chunk + KT - 1) / KT) * KT;         // whole query tiles per workgroup: direct output
+        a.chunk = (int)chunk;
+        const bool direct = (chunk % KT) == 0;
+        a.partial = direct ? nullptr : partial;
+        a.nsplit = 1;
+        const unsigned wgs = (unsigned)((units + chunk - 1) / chunk);
         {
             ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
             if (mode == 0)
-                hipLaunchKernelGGL((gsv4_kernel<Fp16, 2, NV>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((gsv4_kernel<Fp16, 2, NV>), dim3(wgs), dim3(256), 0, stream, a);
             else
-                hipLaunchKernelGGL((gsv4_kernel<Bf16, 1, NV>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((gsv4_kernel<Bf16, 1, NV>), dim3(wgs), dim3(256), 0, stream, a);
         }
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess && a.nsplit > 1) {
+        if (e == hipSuccess && !direct) {
             const long total = (long)nbatch * a.Lq;
-            hipLaunchKernelGGL((gsv_combine_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, nbatch);
+            hipLaunchKernelGGL((gsv4_combine_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
             e = hipGetLastError();
         }
         return e;
