@@ -197,7 +197,7 @@ def test_global_matching_full_size_vs_fp64(ops, ops_fast):
 
 
 @pytest.mark.parametrize('case', ['late_maximum', 'huge_jump', 'all_negative', 'tiny'])
-def test_global_matching_offset_renormalisation(ops, case):
+def test_global_matching_offset_renormalisation(ops, ops_fast, case):
     """The running softmax offset is renormalised lazily (only when a tile's maximum exceeds it by 2^40, on a separate
     path).  Adversarial key orders: the maximum arrives in the last tiles after hundreds of small scores; one jump of more
     than 2^127 (would overflow exp2 if the lazy path were taken); all logits far below zero (the first tile must set a
@@ -224,6 +224,16 @@ def test_global_matching_offset_renormalisation(ops, case):
     assert torch.isfinite(got).all(), case
     mx, mean = err(got, want)
     assert mean < 2e-4 and mx < 5e-3, (case, mx, mean)
+    # bf16 mode (P.V on the matrix pipe, offset shared by a query's two half-waves): same renormalisation paths; the reference
+    # here is the fp64 evaluation of the features ROUNDED AS THE PLANES ARE, so that what is compared is the kernel (bf16
+    # probabilities: 2^-9 relative), not the operand rounding
+    ps = float(ops_fast.lib.um_global_corr_plane_scale(C))            # the planes carry this factor BEFORE the bf16 rounding
+    r0, r1 = (fm0 * ps).bfloat16().double() / ps, (fm1 * ps).bfloat16().double() / ps
+    want_f = hp.global_corr_softmax_flow(r0, r1, False)
+    got_f = ops_fast.global_corr_softmax_flow(f0.contiguous().to(DEV), f1.contiguous().to(DEV), h, w)
+    assert torch.isfinite(got_f).all(), (case, 'fast')
+    mx, mean = err(got_f, want_f)
+    assert mean < 0.25, (case, 'fast', mx, mean)
 
 
 @pytest.mark.parametrize('scale', [0.1, 1.0, 10.0, 100.0])
@@ -898,3 +908,14 @@ def test_convex_upsample(ops, cfg):
     # the same mask in channels-last layout (what um_conv2d_fwd produces): bitwise the same result
     nhwc = mask.permute(0, 2, 3, 1).reshape(b * h * w, -1).contiguous().to(DEV)
     assert torch.equal(ops.convex_upsample(flow.to(DEV), nhwc, factor, is_depth, mask_nhwc=True), got)
+
+
+def test_weight_range_is_checked(ops):
+    """Exact mode stores weights as fp16 planes of w * 2^10: a weight of 64 or more cannot be represented and must be refused
+    when its planes are built, not turned into inf / NaN outputs."""
+    w = torch.full((128, 128), 0.01, device=DEV)
+    ops.weight_planes((w,))                                        # fine
+    bad = w.clone()
+    bad[3, 5] = 70.0
+    with pytest.raises(ValueError, match='does not fit the fp16 operand planes'):
+        ops.weight_planes((bad,))

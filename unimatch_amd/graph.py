@@ -48,12 +48,20 @@ class GraphedUniMatch(torch.nn.Module):
             return self.model(img0, img1, **kw)
         key = (tuple(img0.shape), tuple(img1.shape), str(img0.dtype), tuple(sorted((k, _freeze(v)) for k, v in kw.items())))
         entry = self._graphs.get(key)
+        if entry is None and (kw.get('task') == 'depth' or torch.is_tensor(kw.get('pose'))):
+            # the depth path inverts intrinsics / poses (torch.inverse synchronises): known not to be capturable, never tried
+            entry = self._graphs[key] = False
         if entry is None:
             try:
                 entry = self._capture(img0, img1, kw)
             except RuntimeError as exc:          # an op that cannot be captured (e.g. a library call that syncs)
                 warnings.warn(f'HIP graph capture failed ({exc}); running eagerly for this configuration')
                 entry = False
+                # an aborted capture leaves the stream in an invalidated capture state and may have filled the model's
+                # operand-plane caches from the graph's private memory pool: drain the device and forget them
+                torch.cuda.synchronize()
+                if hasattr(self.model, 'invalidate_weights'):
+                    self.model.invalidate_weights()
             self._graphs[key] = entry
         if entry is False:
             return self.model(img0, img1, **kw)

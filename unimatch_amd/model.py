@@ -405,7 +405,13 @@ class UniMatch(nn.Module):
         attn_type = attn_type if attn_type is not None else ''
         dev = img0.device
 
-        with torch.no_grad():
+        # every launch of the library goes to torch's CURRENT stream and scratch buffers are allocated on the current device:
+        # make the inputs' device current for the whole forward (a model on cuda:1 called while cuda:0 is current)
+        import contextlib
+        guard = torch.cuda.device(dev) if img0.is_cuda else contextlib.nullcontext()
+        if img1.device != dev:
+            raise ValueError(f'img0 is on {dev} and img1 on {img1.device}')
+        with guard, torch.no_grad():
             input_norm = None
             if task == 'flow':                  # stereo / depth loaders normalise already (unimatch.py:122-124)
                 if self.backbone.takes_raw_images(ops, img0):

@@ -143,10 +143,21 @@ class HipOps:
             return hit
         w = (weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)).detach().float().contiguous()
         n, k = w.shape
+        self._check_weight_range(w, self.WSHIFT if self.mode == 0 else 0, 'Linear weight')
         planes = torch.empty(self.lib.um_planes_bytes(n, k, self.mode), dtype=torch.uint8, device=w.device)
         _abi.check(self.lib.um_weight_planes(_ptr(w), _ptr(planes), n, k, self.WSHIFT, self.mode, _stream()),
                    'um_weight_planes')
         return self._cache_put(key, weights, (planes, n, k))
+
+    @staticmethod
+    def _check_weight_range(w, shift, what):
+        """Exact mode stores weights as fp16 hi + lo planes of ``w * 2^shift``: anything at or above 65504 / 2^shift would become
+        inf in the hi plane (and NaN in the output) without a message.  One-time check per cached weight (synchronises once)."""
+        limit = 65504.0 / float(1 << shift)
+        amax = float(w.abs().max()) if w.numel() else 0.0
+        if not amax < limit:
+            raise ValueError(f'{what}: max |w| = {amax:.4g} does not fit the fp16 operand planes (|w| < {limit:.4g} at the '
+                             f'2^{shift} pre-scale; see include/unimatch_hip.h, "Operand range")')
 
     def _check_rows(self, name, t, k):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.shape[1] == k):
@@ -306,6 +317,7 @@ class HipOps:
         cout, cin, kh, kw = weight.shape
         w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous()
         planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, self.CONV_MODE), dtype=torch.uint8, device=w2.device)
+        self._check_weight_range(w2, self.WSHIFT, 'convolution weight')
         _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, self.CONV_MODE, _stream()),
                    'um_weight_planes')
         return self._cache_put(key, (weight,), (planes, cout, cin, kh, kw))
@@ -366,6 +378,7 @@ class HipOps:
         cout, cin, kh, kw = weight.shape
         w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous()
         planes = torch.empty(self.lib.um_planes_bytes(cout, kh * kw * cin, 0), dtype=torch.uint8, device=w2.device)
+        self._check_weight_range(w2, self.WSHIFT, 'convolution weight')
         _abi.check(self.lib.um_weight_planes(_ptr(w2), _ptr(planes), cout, kh * kw * cin, self.WSHIFT, 0, _stream()),
                    'um_weight_planes')
         return planes, cout, cin, kh, kw
@@ -420,6 +433,7 @@ class HipOps:
             wr[:, :, :7, :c] = weight.detach().float().permute(0, 2, 3, 1)
             wr = wr.reshape(cout, 56 * cpp).contiguous()
             wp = torch.empty(self.lib.um_planes_bytes(cout, 56 * cpp, 0), dtype=torch.uint8, device=weight.device)
+            self._check_weight_range(wr, self.WSHIFT, 'convolution weight')
             _abi.check(self.lib.um_weight_planes(_ptr(wr), _ptr(wp), cout, 56 * cpp, self.WSHIFT, 0, _stream()), 'um_weight_planes')
             hit = self._cache_put(key, (weight,), wp)
         scratch = torch.empty(self.lib.um_conv7_planes_bytes(b, h, w, stride), dtype=torch.uint8, device=image.device)
@@ -469,6 +483,7 @@ class HipOps:
             wr[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
             wr = wr.reshape(cout, 224).contiguous()
             wp = torch.empty(self.lib.um_planes_bytes(cout, 224, 0), dtype=torch.uint8, device=weight.device)
+            self._check_weight_range(wr, self.WSHIFT, 'convolution weight')
             _abi.check(self.lib.um_weight_planes(_ptr(wr), _ptr(wp), cout, 224, self.WSHIFT, 0, _stream()), 'um_weight_planes')
             hit = self._cache_put(key, (weight,), wp)
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
