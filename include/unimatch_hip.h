@@ -295,6 +295,25 @@ int um_local_corr_with_flow(const float* f0, const float* f1, const float* flow,
 int um_local_corr_with_flow_planes(const float* f0, const float* f1, const float* flow, void* planes_out, int ld, long plane_rows,
                                    int batch, int h, int w, int channels, int radius, void* stream);
 
+/* The same cost volume on the matrix cores for locally coherent flow (csrc/local_corr_mfma.hip): an 8 x 4 pixel tile whose
+ * 10 x 10 integer neighbourhoods fit a 32 x 24 window of f1 gets every dot product from one 32 x 32 x 128 MFMA product per
+ * window row; other tiles (motion boundaries) take the pixel-at-a-time path inside the same kernel.  The refinement loop
+ * (unimatch/unimatch.py:315-331) calls matching.py:86-123 with the SAME feature0 / feature1 in every iteration, so their fp16
+ * hi | lo operand planes are built once per scale:
+ *   um_local_corr_feat_planes_bytes(...)                bytes of `feat_planes`
+ *   um_local_corr_feat_planes(f0, f1, feat_planes, ...) fill it ([B, h*w, 128] fp32 tokens in)
+ *   um_local_corr_with_flow_feat_supported(...)         1 for radius 4 on maps of whole 8 x 4 tiles
+ *   um_local_corr_with_flow_feat(...)                   exactly one of `cost` ([B, 81, h, w] fp32) and `planes_out` (as
+ *                                                       um_local_corr_with_flow_planes) non-null; flags bit 0 = every tile on
+ *                                                       the pixel-at-a-time path (A/B timing). */
+size_t um_local_corr_feat_planes_bytes(int batch, int h, int w, int channels);
+int um_local_corr_feat_planes(const float* f0, const float* f1, void* feat_planes, int batch, int h, int w, int channels,
+                              void* stream);
+int um_local_corr_with_flow_feat_supported(int h, int w, int channels, int radius);
+int um_local_corr_with_flow_feat(const float* f0, const float* f1, const void* feat_planes, const float* flow, float* cost,
+                                 void* planes_out, int ld, long plane_rows, int batch, int h, int w, int channels, int radius,
+                                 int flags, void* stream);
+
 /* (2r+1)^2 local self-attention propagation with zero-padded keys/values (out-of-image neighbours
  * have logit 0, value 0 and take part in the softmax).
  * Replaces the core of unimatch/attention.py:217-253 forward_local_window_attn. */

@@ -919,3 +919,49 @@ def test_weight_range_is_checked(ops):
     bad[3, 5] = 70.0
     with pytest.raises(ValueError, match='does not fit the fp16 operand planes'):
         ops.weight_planes((bad,))
+
+
+@pytest.mark.parametrize('kind', ['smooth', 'noisy', 'mixed', 'border'])
+def test_cost_volume_matrix_core_path(ops, kind):
+    """um_local_corr_with_flow_feat: 8 x 4 pixel tiles with coherent flow go through the matrix cores (one 32 x 32 x 128 product
+    per window row, split-fp16 operands), the others through the pixel-at-a-time path of the same kernel.  Against the fp64
+    oracle (matching.py:86-123 restated), against the same kernel with every tile forced onto the VALU path, and both output
+    forms.  'border': flows that push whole windows out of the image (zeros padding) and exactly integer flows."""
+    b, h, w = 2, 32, 48
+    f0, f1 = rnd(130, b, C, h, w), rnd(131, b, C, h, w)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    smooth = torch.stack([2.3 * torch.sin(yy / 5.0) + 0.05 * xx, 1.7 * torch.cos(xx / 7.0) - 0.5], 0)[None].repeat(b, 1, 1, 1).float()
+    if kind == 'smooth':
+        flow = smooth
+    elif kind == 'noisy':
+        flow = rnd(132, b, 2, h, w, scale=9.0)
+    elif kind == 'mixed':
+        flow = smooth.clone()
+        flow[:, :, :, 24:] += rnd(133, b, 2, h, 24, scale=12.0)           # right half incoherent
+        flow[:, :, 8:12, :8] += 3.1                                       # a coherent tile with a different motion
+    else:
+        flow = smooth.clone()
+        flow[0, 0] += 45.0                                                # image 0: everything samples right of the image
+        flow[1] = torch.round(flow[1])                                    # image 1: integer flows (weights 1, 0, 0, 0)
+        flow[1, 1, :6] -= 7.0                                             # top rows sample above the image
+    flow = flow.contiguous()
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    want = hp.local_corr_with_flow(f0.double(), f1.double(), flow.double(), 4)
+    assert ops._k4_feat_planes(t0, t1, h, w, 4) is not None               # the matrix-core entry point serves this geometry
+    got = ops.local_corr_with_flow(t0, t1, flow.to(DEV), h, w, 4)
+    scale = max(1.0, want.abs().max().item())
+    assert err(got, want)[1] < 3e-6 * scale, (kind, err(got, want))
+    ops.k4_flags = 1
+    try:
+        valu = ops.local_corr_with_flow(t0, t1, flow.to(DEV), h, w, 4)
+    finally:
+        ops.k4_flags = 0
+    assert err(valu, want)[1] < 3e-6 * scale
+    rows = b * h * w
+    buf = ops.planes_buffer(rows, 96)
+    ops.local_corr_with_flow_planes(t0, t1, flow.to(DEV), h, w, 4, buf, 96)
+    pl = buf.view(torch.float16).view(2, rows + 1, 96).float()
+    back = pl.sum(0)[:rows, :81].view(b, h, w, 81).permute(0, 3, 1, 2)
+    assert (back - got).abs().max().item() < 2e-6 * scale
+    assert torch.equal(pl[:, :rows, 81:], torch.zeros(2, rows, 15, device=DEV))
+    assert torch.equal(pl[:, rows], torch.zeros(2, 96, device=DEV))

@@ -1,11 +1,15 @@
 """Run the five BASELINE.json configs at their full sizes on one GPU (diagnostic; bench.py measures configs[1]).
 
-    python tools/bench_configs.py [--only 1,5] [--steps 20]
+    python tools/bench_configs.py [--only 1,5] [--steps 20] [--weights damped|conditioned]
+
+--weights conditioned: synth.CONDITIONED (soft softmaxes, small refinement steps) -- the refinement flow is then locally
+coherent, as a trained model's is, and the cost volume runs on the matrix cores (csrc/local_corr_mfma.hip); with the default
+random-init statistics the scale-1 flow is incoherent everywhere and every tile takes the pixel-at-a-time path.
 """
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from unimatch_amd import UniMatch
-from unimatch_amd.synth import CONFIGS, synth_camera, synth_images, synth_state_dict
+from unimatch_amd.synth import CONDITIONED, CONFIGS, synth_camera, synth_images, synth_state_dict
 RUNS = [  # (label, config, batch, H, W)
     ('cfg1 GMFlow-s1 1x320x448', 'gmflow_s1', 1, 320, 448),
     ('cfg2 GMFlow-s1 8x512x768', 'gmflow_s1', 8, 512, 768),
@@ -16,12 +20,14 @@ RUNS = [  # (label, config, batch, H, W)
 ARGV = sys.argv[1:]
 ONLY = [int(v) for v in ARGV[ARGV.index('--only') + 1].split(',')] if '--only' in ARGV else [1, 2, 3, 4, 5]
 STEPS = int(ARGV[ARGV.index('--steps') + 1]) if '--steps' in ARGV else 5
+WEIGHTS = ARGV[ARGV.index('--weights') + 1] if '--weights' in ARGV else 'damped'
+WKW = CONDITIONED if WEIGHTS == 'conditioned' else dict(refine_gain=0.02)
 for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
     if idx not in ONLY:
         continue
     ck, fk = CONFIGS[name]
     model = UniMatch(**ck).eval()
-    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
+    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, **WKW))
     model = model.cuda()
     i0, i1 = synth_images(b, hh, ww, seed=3, kind='shift', normalized=(fk['task'] != 'flow'))
     kw = dict(fk)

@@ -1,0 +1,329 @@
+// K4 on the matrix cores: local cost volume at flow-displaced positions for locally coherent flow.   gfx950 / wave64 / MFMA
+//
+//   cost[b, (dy, dx), p] = < f0(p), bilinear f1(p + (dx, dy) + flow(p)) > / sqrt(C),   |dx|, |dy| <= 4, zeros outside the image
+//   (unimatch/matching.py:86-123, called from the refinement loop unimatch/unimatch.py:315-331)
+//
+// local_corr_with_flow_kernel (local_ops.hip) turns the 81 x 4 bilinear gathers of a pixel into the 100 dot products of its
+// 10 x 10 integer neighbourhood plus 81 four-tap blends, and is bound by the L2 -> CU traffic of those neighbour rows (51 KB
+// per pixel, 0.59 ms per call at 4 x 128 x 192).  A pixel alone is a GEMV -- nothing for the matrix cores -- but the 10 x 10
+// neighbourhoods of ADJACENT pixels overlap almost completely when the flow is locally coherent, which is what a trained model
+// produces (with the conditioned weights of unimatch_amd/synth.py 96-98 % of the 32-pixel groups of config 4 spread their integer
+// flow over <= 6 pixels; at random init the flow is incoherent everywhere, profiles/r02_k4_flow_coherence.txt).  So:
+//   * a wave owns an 8 x 4 pixel tile; the union of its neighbourhoods is a (8 + 9 + rx) x (4 + 9 + ry) window of f1;
+//   * per window ROW one 32 x 32 x 128 product S^T = F1row . F0^T on the matrix cores (A = up to 32 window positions of the
+//     row, read straight from the fp16 hi | lo operand planes of f1 in L2; B = the tile's 32 pixels; exact mode: 3 products),
+//     24 MFMAs per row, <= 24 rows: every dot product a pixel needs (and ~3x as many it does not) at ~10 KB per pixel;
+//   * the accumulators are scattered to the per-pixel [10 x 10] dot tables in LDS (lane = pixel: the slot of a register is a
+//     per-lane base plus a constant), then the same four-tap blends as the VALU kernel, and the same two output forms
+//     ([B, 81, h, w] fp32, or the channels-last operand planes of the motion encoder's 1x1 convolution);
+//   * tiles whose window does not fit 32 x 24 (motion boundaries; everything at random init) take the pixel-at-a-time VALU
+//     path inside the same kernel -- the dot products of that path are the VALU kernel's.
+// The feature planes are split once per scale (um_local_corr_feat_planes) and serve every refinement iteration.
+#include "common.h"
+#include "planes.h"
+
+extern void um_set_error(const char* fmt, ...);
+
+#define K4M_RADIUS 4
+#define K4M_KW 9
+#define K4M_N1 10
+#define K4M_TAPS 81
+#define K4M_TW 8
+#define K4M_TH 4
+#define K4M_MAXROWS 24
+
+struct K4mArgs {
+    const float* f0;             // [B][L][128] fp32 tokens (VALU path)
+    const float* f1;
+    const unsigned short* fp0;   // operand planes [2][B*L][128] fp16 hi | lo of f0, f1 (MFMA path)
+    const unsigned short* fp1;
+    long plane_stride;
+    const float* flow;           // [B][2][h][w]
+    float* cost;                 // [B][81][h][w]   (or null)
+    unsigned short* planes;      // [2][rows + 1][ld]   (or null)
+    long out_plane_stride;
+    int ld;
+    int batch, h, w;
+    int force_valu;              // diagnostics: every tile on the VALU path
+};
+
+__device__ __forceinline__ int k4m_wave_min(int v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = min(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ int k4m_wave_max(int v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = max(v, __shfl_xor(v, s));
+    return v;
+}
+
+__global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
+    // per wave: the [slot][pixel] dot tables (one spare slot: the blend reads one past a row); the [tap][pixel] output tile
+    // takes the same storage once the tables are consumed (the blends are held in registers across a wave barrier).
+    // Occupancy is deliberately low (one wave per SIMD: 300+ registers for the double-buffered window rows): measured, both
+    // paths are bound by L2 -> CU traffic and lose with more waves in flight (2-3 waves per SIMD: pixel path +6...+20 %).
+    __shared__ float dots_s[2][(K4M_N1 * K4M_N1 + 1) * 32];
+    __shared__ float pix_s[2][K4M_N1 * K4M_N1 + 4];              // VALU path: the dot table of one pixel
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, n = lane & 31;
+    const int L = a.h * a.w;
+    const int tiles_x = a.w / K4M_TW, tiles_y = a.h / K4M_TH;
+    const int ntile = a.batch * tiles_x * tiles_y;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    float* dots = dots_s[wave];
+    float* outt = dots_s[wave];
+
+    for (int tile = blockIdx.x * 2 + wave; tile < ntile; tile += gridDim.x * 2) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int tt = tile - b * (tiles_x * tiles_y);
+        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int x = tx * K4M_TW + (n & 7), y = ty * K4M_TH + (n >> 3);
+        const int p = y * a.w + x;
+        const float px = (float)x + a.flow[((long)b * 2 + 0) * L + p];
+        const float py = (float)y + a.flow[((long)b * 2 + 1) * L + p];
+        const float fbx = floorf(px), fby = floorf(py);
+        const float wx = px - fbx, wy = py - fby;
+        // clamp far-away bases so the int conversion is defined; such samples are all-zero anyway
+        const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f);
+        const int by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
+        const int ux0 = k4m_wave_min(bx) - K4M_RADIUS, ux1 = k4m_wave_max(bx) - K4M_RADIUS + K4M_N1 - 1;
+        const int uy0 = k4m_wave_min(by) - K4M_RADIUS, uy1 = k4m_wave_max(by) - K4M_RADIUS + K4M_N1 - 1;
+        const int bw = ux1 - ux0 + 1, bh = uy1 - uy0 + 1;
+        const bool coherent = !a.force_valu && bw <= 32 && bh <= K4M_MAXROWS;     // wave uniform
+
+        if (coherent) {
+            // ---- B operand: the tile's 32 pixels (f0), both planes
+            i16x8 qf[2][8];
+            {
+                const unsigned short* q0 = a.fp0 + ((long)b * L + p) * UM_CHANNELS + 8 * half;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(q0 + pl * a.plane_stride + 16 * ks);
+            }
+            // window position of this lane in a row, its validity, and the per-lane part of the scatter address
+            const int xx = ux0 + n;
+            const bool colok = n < bw && xx >= 0 && xx < a.w;
+            const int dx0 = ux0 - (bx - K4M_RADIUS) + 4 * half;            // ix of accumulator register r = dx0 + c_r
+            auto load_row = [&](int yy, i16x8 (&ka)[2][8]) __attribute__((always_inline)) {
+                const bool ok = colok && yy >= 0 && yy < a.h;
+                const unsigned short* k0 = a.fp1 + ((long)b * L + (ok ? yy * a.w + xx : 0)) * UM_CHANNELS + 8 * half;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        i16x8 v = ld_global_16B(k0 + pl * a.plane_stride + 16 * ks);
+                        if (!ok) v = i16x8{0, 0, 0, 0, 0, 0, 0, 0};                  // zeros padding (matching.py:113)
+                        ka[pl][ks] = v;
+                    }
+            };
+            auto do_row = [&](int yy, const i16x8 (&ka)[2][8]) __attribute__((always_inline)) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc = Fp16::mfma(ka[1][ks], qf[0][ks], acc);               // lo_k . hi_q
+                    acc = Fp16::mfma(ka[0][ks], qf[1][ks], acc);               // hi_k . lo_q
+                    acc = Fp16::mfma(ka[0][ks], qf[0][ks], acc);               // hi_k . hi_q
+                }
+                const int iy = yy - (by - K4M_RADIUS);
+                if ((unsigned)iy < (unsigned)K4M_N1) {
+                    float* d = dots + (iy * K4M_N1 + dx0) * 32 + n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cr = (r & 3) + 8 * (r >> 2);
+                        if ((unsigned)(dx0 + cr) < (unsigned)K4M_N1) d[cr * 32] = acc[r];
+                    }
+                }
+            };
+            i16x8 kaA[2][8], kaB[2][8];                              // the next row's loads fly under this row's MFMAs
+            load_row(uy0, kaA);
+            for (int r0 = 0; r0 < bh; r0 += 2) {
+                if (r0 + 1 < bh) load_row(uy0 + r0 + 1, kaB);
+                do_row(uy0 + r0, kaA);
+                if (r0 + 1 < bh) {
+                    if (r0 + 2 < bh) load_row(uy0 + r0 + 2, kaA);
+                    do_row(uy0 + r0 + 1, kaB);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- blends: lanes 0-31 take tap columns 0..4, lanes 32-63 columns 5..8 of every tap row
+            const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy);
+            const float w10 = (1.f - wx) * wy, w11 = wx * wy;
+            const int col0 = 5 * half;
+            float d0[6], d1[6], res[K4M_KW][5];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d0[c] = dots[(col0 + c) * 32 + n];
+#pragma unroll
+            for (int trow = 0; trow < K4M_KW; ++trow) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) d1[c] = dots[((trow + 1) * K4M_N1 + col0 + c) * 32 + n];
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    res[trow][j] = (w00 * d0[j] + w01 * d0[j + 1] + w10 * d1[j] + w11 * d1[j + 1]) * scale;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) d0[c] = d1[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                        // every lane has read its dots: the storage becomes the tile
+#pragma unroll
+            for (int trow = 0; trow < K4M_KW; ++trow)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (col0 + j < K4M_KW) outt[(trow * K4M_KW + col0 + j) * 32 + n] = res[trow][j];
+        } else {
+            // ---- VALU path, one pixel at a time: lanes = 16 neighbour slots x 4 channel quarters (as local_ops.hip)
+            const int slot = lane >> 2, quarter = lane & 3;
+            for (int j = 0; j < 32; ++j) {
+                const int jbx = __shfl(bx, j), jby = __shfl(by, j);
+                const float jwx = __shfl(wx, j), jwy = __shfl(wy, j);
+                const int jp = __shfl(p, j);
+                f32x4 av[8];
+                {
+                    const float* ap = a.f0 + ((long)b * L + jp) * UM_CHANNELS + 32 * quarter;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) av[i] = reinterpret_cast<const f32x4*>(ap)[i];
+                }
+                for (int r = 0; r * 16 < K4M_N1 * K4M_N1; ++r) {
+                    const int t = r * 16 + slot;
+                    const int iy = t / K4M_N1, ix = t - iy * K4M_N1;
+                    const int yy = jby + iy - K4M_RADIUS, xx = jbx + ix - K4M_RADIUS;
+                    const bool ok = t < K4M_N1 * K4M_N1 && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+                    float d = 0.f;
+                    if (ok) {
+                        const float* bp = a.f1 + ((long)b * L + yy * a.w + xx) * UM_CHANNELS + 32 * quarter;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const f32x4 bv = reinterpret_cast<const f32x4*>(bp)[i];
+                            d = __builtin_fmaf(av[i][0], bv[0], d);
+                            d = __builtin_fmaf(av[i][1], bv[1], d);
+                            d = __builtin_fmaf(av[i][2], bv[2], d);
+                            d = __builtin_fmaf(av[i][3], bv[3], d);
+                        }
+                    }
+                    d += __shfl_xor(d, 1);
+                    d += __shfl_xor(d, 2);
+                    if (quarter == 0 && t < K4M_N1 * K4M_N1) pix_s[wave][t] = d;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float w00 = (1.f - jwx) * (1.f - jwy), w01 = jwx * (1.f - jwy);
+                const float w10 = (1.f - jwx) * jwy, w11 = jwx * jwy;
+                for (int k = lane; k < K4M_TAPS; k += 64) {
+                    const int trow = k / K4M_KW, tcol = k - trow * K4M_KW;
+                    const float* dd = &pix_s[wave][trow * K4M_N1 + tcol];
+                    const float v = w00 * dd[0] + w01 * dd[1] + w10 * dd[K4M_N1] + w11 * dd[K4M_N1 + 1];
+                    outt[k * 32 + j] = v * scale;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- output: the [81][32] tile of this wave
+        const long pix0 = (long)b * L;
+        if (a.planes) {
+            // channels-last operand planes for um_conv2d_ex: pixel row = ld channels, taps first, zeros up to ld
+            const int pairs = a.ld >> 1;
+            for (int idx = lane; idx < pairs * 32; idx += 64) {
+                const int j = idx / pairs, c = (idx - j * pairs) * 2;
+                const long pid = pix0 + (long)(ty * K4M_TH + (j >> 3)) * a.w + tx * K4M_TW + (j & 7);
+                const float v0 = c < K4M_TAPS ? outt[c * 32 + j] : 0.f, v1 = c + 1 < K4M_TAPS ? outt[(c + 1) * 32 + j] : 0.f;
+                const unsigned hh = Fp16::pack2(v0, v1);
+                const f32x2 u = Fp16::unpack2(hh);
+                *reinterpret_cast<unsigned*>(a.planes + pid * a.ld + c) = hh;
+                *reinterpret_cast<unsigned*>(a.planes + a.out_plane_stride + pid * a.ld + c) = Fp16::pack2(v0 - u[0], v1 - u[1]);
+            }
+        } else {
+            for (int idx = lane; idx < K4M_TAPS * 32; idx += 64) {
+                const int k = idx >> 5, j = idx & 31;
+                const int pp = (ty * K4M_TH + (j >> 3)) * a.w + tx * K4M_TW + (j & 7);
+                a.cost[((long)b * K4M_TAPS + k) * L + pp] = outt[k * 32 + j];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static size_t k4m_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// bytes of the feature planes of one scale: [f0 | f1], each [2][B * L][128] fp16
+extern "C" size_t um_local_corr_feat_planes_bytes(int batch, int h, int w, int channels) {
+    if (batch <= 0 || h <= 0 || w <= 0 || channels != UM_CHANNELS) return 0;
+    return 2 * k4m_align256(planes_bytes((long)batch * h * w, 0));
+}
+
+// split f0, f1 ([B, h*w, 128] fp32 tokens) into the operand planes the matrix-core cost volume reads; once per scale
+extern "C" int um_local_corr_feat_planes(const float* f0, const float* f1, void* feat_planes, int batch, int h, int w, int channels,
+                                         void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!f0 || !f1 || !feat_planes || batch <= 0 || h <= 0 || w <= 0 || channels != UM_CHANNELS) {
+        um_set_error("um_local_corr_feat_planes: bad argument");
+        return -1;
+    }
+    const long rows = (long)batch * h * w;
+    unsigned char* ws = (unsigned char*)feat_planes;
+    hipError_t e;
+    if ((e = launch_split_planes(f0, (unsigned short*)ws, rows, 1.f, 0, stream)) != hipSuccess) return (int)e;
+    if ((e = launch_split_planes(f1, (unsigned short*)(ws + k4m_align256(planes_bytes(rows, 0))), rows, 1.f, 0, stream)) != hipSuccess)
+        return (int)e;
+    return 0;
+}
+
+// 1 when um_local_corr_with_flow_feat serves this geometry (radius 4, maps of whole 8 x 4 pixel tiles)
+extern "C" int um_local_corr_with_flow_feat_supported(int h, int w, int channels, int radius) {
+    return (channels == UM_CHANNELS && radius == K4M_RADIUS && h > 0 && w > 0 && h % K4M_TH == 0 && w % K4M_TW == 0) ? 1 : 0;
+}
+
+// Local cost volume (matching.py:86-123) with the feature planes of um_local_corr_feat_planes.  Exactly one of `cost`
+// ([B, 81, h, w] fp32) and `planes_out` (channels-last operand planes [2][plane_rows][ld], as um_local_corr_with_flow_planes)
+// is non-null.  mode bit 0: force the VALU path for every tile (diagnostics / A-B timing).
+extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, const void* feat_planes, const float* flow, float* cost,
+                                            void* planes_out, int ld, long plane_rows, int batch, int h, int w, int channels,
+                                            int radius, int flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!f0 || !f1 || !feat_planes || !flow || (!cost == !planes_out) || batch <= 0) {
+        um_set_error("um_local_corr_with_flow_feat: null pointer, or not exactly one output");
+        return -1;
+    }
+    if (!um_local_corr_with_flow_feat_supported(h, w, channels, radius)) {
+        um_set_error("um_local_corr_with_flow_feat: radius %d on a %dx%d map is not served (radius 4, h %% 4 == 0, w %% 8 == 0)", radius, h, w);
+        return -2;
+    }
+    if (planes_out && (ld < K4M_TAPS + 1 || (ld & 1) || plane_rows < (long)batch * h * w)) {
+        um_set_error("um_local_corr_with_flow_feat: bad planes geometry (ld=%d rows=%ld)", ld, plane_rows);
+        return -1;
+    }
+    const long rows = (long)batch * h * w;
+    K4mArgs a;
+    a.f0 = f0;
+    a.f1 = f1;
+    a.fp0 = (const unsigned short*)feat_planes;
+    a.fp1 = (const unsigned short*)((const unsigned char*)feat_planes + k4m_align256(planes_bytes(rows, 0)));
+    a.plane_stride = rows * UM_CHANNELS;
+    a.flow = flow;
+    a.cost = cost;
+    a.planes = (unsigned short*)planes_out;
+    a.out_plane_stride = plane_rows * ld;
+    a.ld = ld;
+    a.batch = batch;
+    a.h = h;
+    a.w = w;
+    a.force_valu = flags & 1;
+    const long ntile = rows / 32;
+    long blocks = (ntile + 1) / 2;
+    if (blocks > 4096) blocks = 4096;
+    {
+        ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
+        hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
+    }
+    return (int)hipGetLastError();
+}

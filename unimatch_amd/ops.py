@@ -463,9 +463,35 @@ class HipOps:
         _check_tokens('f0', f0, tokens=h * w)
         _check_tokens('f1', f1, b, l)
         flow = flow.contiguous()
+        feat = self._k4_feat_planes(f0, f1, h, w, radius)
+        if feat is not None:
+            code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
+                _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), None, _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius,
+                self.k4_flags, _stream()))
+            _abi.check(code, 'um_local_corr_with_flow_feat')
+            return
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_planes(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius, _stream()))
         _abi.check(code, 'um_local_corr_with_flow_planes')
+
+    k4_mfma = os.environ.get('UM_K4_MFMA', '1') != '0'     # cost volume on the matrix cores where the flow is coherent
+    k4_flags = 1 if os.environ.get('UM_K4_FORCE_VALU') == '1' else 0
+
+    def _k4_feat_planes(self, f0, f1, h, w, radius):
+        """fp16 hi | lo operand planes of (f0, f1) for um_local_corr_with_flow_feat, or None where that kernel does not apply.
+        The refinement loop passes the same two tensors in every iteration: one entry, keyed by identity and version."""
+        if not self.k4_mfma or not self.lib.um_local_corr_with_flow_feat_supported(h, w, f0.shape[2], radius):
+            return None
+        key = (id(f0), f0._version, f0.data_ptr(), id(f1), f1._version, f1.data_ptr(), tuple(f0.shape))
+        hit = getattr(self, '_k4_feat', None)
+        if hit is not None and hit[0] == key and hit[1]() is f0 and hit[2]() is f1:
+            return hit[3]
+        b, l, c = f0.shape
+        feat = torch.empty(self.lib.um_local_corr_feat_planes_bytes(b, h, w, c), dtype=torch.uint8, device=f0.device)
+        _abi.check(self.lib.um_local_corr_feat_planes(_ptr(f0), _ptr(f1), _ptr(feat), b, h, w, c, _stream()),
+                   'um_local_corr_feat_planes')
+        self._k4_feat = (key, weakref.ref(f0), weakref.ref(f1), feat)
+        return feat
 
     def stem_conv(self, image, weight, norm_mean_std=None, stats=True):
         """The encoder's 7x7/2 stem on ``um_stem_conv_fwd``: fp32 NCHW image ``[b,3,h,w]`` -> fp32 NHWC ``[b*ho*wo, cout]``.
@@ -657,6 +683,12 @@ class HipOps:
         k = 2 * radius + 1
         out = torch.empty((b, k * k, h, w), dtype=torch.float32, device=f0.device)
         meta = {'flops': 2.0 * b * l * (k + 1) ** 2 * c, 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l + 4.0 * k * k * b * l}
+        feat = self._k4_feat_planes(f0, f1, h, w, radius)
+        if feat is not None:
+            code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
+                _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), _ptr(out), None, 0, 0, b, h, w, c, radius, self.k4_flags, _stream()), meta)
+            _abi.check(code, 'um_local_corr_with_flow_feat')
+            return out
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(out), b, h, w, c, radius, _stream()), meta)
         _abi.check(code, 'um_local_corr_with_flow')
