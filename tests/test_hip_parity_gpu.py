@@ -143,6 +143,22 @@ def test_window_attention_properties_at_config2_size(ops, ops_fast):
     assert (ab - (0.5 * a - 2.0 * b)).abs().max().item() < 2e-5
 
 
+def test_window_attention_config2_size_vs_fp64(ops, ops_fast):
+    """The attention core at BASELINE config 2's layer geometry (64x96 map, 2x2 windows of 1536 tokens, cyclic shift 16/24 with
+    the -100 masks; 2 streams to bound the CPU time) against the fp64 oracle: exact mode within 2x of what fp32 arithmetic
+    gives, bf16 mode in its ballpark (full-size kernel-vs-oracle comparisons, not only properties)."""
+    s, h, w, wh, ww = 2, 64, 96, 32, 48
+    q, k, v = rnd(44, s, h * w, C, scale=1.5), rnd(45, s, h * w, C, scale=1.5), rnd(46, s, h * w, C)
+    for (sh, sw) in ((0, 0), (16, 24)):
+        want = hp.window_attention(q.double(), k.double(), v.double(), h, w, wh, ww, sh, sw)
+        f32 = hp.window_attention(q, k, v, h, w, wh, ww, sh, sw)
+        got = ops.window_attention(q.to(DEV), k.to(DEV), v.to(DEV), h, w, wh, ww, sh, sw)
+        e_gpu, e_f32 = err(got, want), err(f32, want)
+        assert e_gpu[1] <= 2.0 * e_f32[1] + 1e-6 and e_gpu[0] <= 2.0 * e_f32[0] + 1e-7, ((sh, sw), e_gpu, e_f32)
+        fast = ops_fast.window_attention(q.to(DEV), k.to(DEV), v.to(DEV), h, w, wh, ww, sh, sw)
+        assert err(fast, want)[1] < 3e-2 * want.abs().max().item() + 1e-3
+
+
 # ------------------------------------------------------------------ global matching / propagation
 @pytest.mark.parametrize('tag', ['soft', 'peaky'])
 def test_global_matching_golden(ops, ops_fast, golden, tag):
