@@ -212,13 +212,14 @@ def test_global_matching_full_size_vs_fp64(ops, ops_fast):
     assert torch.isfinite(fast).all() and err(fast, want[:b])[1] < 0.5      # bf16 operands on +-150 logits: ballpark only
 
 
+@pytest.mark.parametrize('b', [1, 36])           # 1 sample: gsv3_kernel (small launch); 36: gsv4_kernel (>= 8 key tiles per CU)
 @pytest.mark.parametrize('case', ['late_maximum', 'huge_jump', 'all_negative', 'tiny'])
-def test_global_matching_offset_renormalisation(ops, ops_fast, case):
+def test_global_matching_offset_renormalisation(ops, ops_fast, case, b):
     """The running softmax offset is renormalised lazily (only when a tile's maximum exceeds it by 2^40, on a separate
     path).  Adversarial key orders: the maximum arrives in the last tiles after hundreds of small scores; one jump of more
     than 2^127 (would overflow exp2 if the lazy path were taken); all logits far below zero (the first tile must set a
     NEGATIVE-score offset or everything underflows); logits ~1e-3 (a flat softmax: every key matters)."""
-    b, h, w = 1, 24, 40                                            # L = 960 = 15 key tiles
+    h, w = 24, 40                                                  # L = 960 = 15 key tiles
     L = h * w
     f0, f1 = rnd(70, b, L, C), rnd(71, b, L, C)
     if case == 'late_maximum':
@@ -250,6 +251,18 @@ def test_global_matching_offset_renormalisation(ops, ops_fast, case):
     assert torch.isfinite(got_f).all(), (case, 'fast')
     mx, mean = err(got_f, want_f)
     assert mean < 0.25, (case, 'fast', mx, mean)
+
+
+def test_global_matching_chunks_longer_than_a_query_tile(ops):
+    """gsv4's stream-K decomposition with MORE (batch x query tile) rows than CUs: a workgroup's chunk is then longer than one
+    query tile's key range and not a multiple of it, so chunks start and end in mid-tile and carry up to three segments
+    (tail of one query tile, a whole one, head of the next).  130 samples of 16 x 32 tokens: 2080 units, chunks of 9 > KT = 8."""
+    b, h, w = 130, 16, 32
+    f0, f1 = rnd(90, b, C, h, w, scale=0.7), rnd(91, b, C, h, w, scale=0.7)
+    want = hp.global_corr_softmax_flow(f0.double(), f1.double(), False)
+    got = ops.global_corr_softmax_flow(tok(f0).to(DEV), tok(f1).to(DEV), h, w)
+    mx, mean = err(got, want)
+    assert mean < 2e-5 and mx < 1e-3, (mx, mean)
 
 
 @pytest.mark.parametrize('scale', [0.1, 1.0, 10.0, 100.0])

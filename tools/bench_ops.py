@@ -147,6 +147,14 @@ def main():
         val = torch.randn(B, 2, h, w, device=dev, generator=g)
         run('global propagation cfg2 B=8 L=6144', lambda: ops.prop_global(f0, f1, val, h, w),
             B * (2.0 * L * L * C + 4.0 * L * L), lib, iters, 'gsv', issued)
+        if '--quick' not in args:
+            # config 5 (depth): 16 samples of 60x80 = 4800 tokens, one value channel; config 1: one sample of 40x56
+            for tag, (B5, h5, w5, vch) in (('cfg5 B=16 L=4800 (depth)', (16, 60, 80, 1)), ('cfg1 B=1 L=2240', (1, 40, 56, 2))):
+                L5 = h5 * w5
+                q5, k5 = (torch.randn(B5, L5, C, device=dev, generator=g) * 3 for _ in range(2))
+                v5 = torch.randn(B5, vch, h5, w5, device=dev, generator=g)
+                run(f'global propagation {tag}', lambda: ops.prop_global(q5, k5, v5, h5, w5),
+                    B5 * (2.0 * L5 * L5 * C + 2.0 * vch * L5 * L5), lib, iters, 'gsv', issued)
     if 'local' in what:
         B, h, w = 4, 128, 192
         L = h * w

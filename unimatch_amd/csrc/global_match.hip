@@ -1179,7 +1179,10 @@ static int gsv_num_cus() {
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
     const int ver = gsv_version();
-    if (!CAUSAL && ver == 4 && a.Lk % 64 == 0 && a.Lk >= 512) {
+    // gsv4 wants every CU busy with a chunk of >= 8 key tiles of a 256-query tile; smaller launches (config 1: one sample of
+    // 2240 tokens = 315 units) are better served by gsv3's 128-query workgroups with split keys (0.021 against 0.032 ms)
+    const long units4 = (long)nbatch * ((a.Lq + 255) / 256) * (a.Lk / 64);
+    if (!CAUSAL && ver == 4 && a.Lk % 64 == 0 && a.Lk >= 512 && units4 >= 8L * gsv_num_cus()) {
         const int KT = a.Lk / 64;
         a.nbatch = nbatch;
         a.qtiles = (a.Lq + 255) / 256;
@@ -1188,7 +1191,8 @@ static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hi
         const long min_chunk = (KT + GSV_MAX_SPLIT - 3) / (GSV_MAX_SPLIT - 2);     // at most GSV_MAX_SPLIT segments per query tile
         if (chunk < min_chunk) chunk = min_chunk;
         if (chunk < 8) chunk = 8;
-        if (!partial || chunk > KT) chunk = ((chunk + KT - 1) / KT) * KT;         // whole query tiles per workgroup: direct output
+        static const bool whole = [] { const char* e = getenv("UM_GSV4_WHOLE_TILES"); return e && *e == '1'; }();   // A/B timing
+        if (!partial || (whole && chunk > KT)) chunk = ((chunk + KT - 1) / KT) * KT;   // no partial buffer: whole query tiles per workgroup
         a.chunk = (int)chunk;
         const bool direct = (chunk % KT) == 0;
         a.partial = direct ? nullptr : partial;
