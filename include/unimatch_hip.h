@@ -310,9 +310,14 @@ size_t um_local_corr_feat_planes_bytes(int batch, int h, int w, int channels);
 int um_local_corr_feat_planes(const float* f0, const float* f1, void* feat_planes, int batch, int h, int w, int channels,
                               void* stream);
 int um_local_corr_with_flow_feat_supported(int h, int w, int channels, int radius);
+/* um_local_corr_softmax (2-D, radius 4, maps of whole 8 x 4 tiles) on the same kernel: every pixel's 81 taps are its own 9 x 9
+ * neighbourhood, so the whole map takes the matrix-core path.  workspace: um_local_corr_feat_planes_bytes(). */
+int um_local_corr_softmax_mfma(const float* f0, const float* f1, float* out, int batch, int h, int w, int channels, int radius,
+                               void* workspace, size_t workspace_bytes, void* stream);
 int um_local_corr_with_flow_feat(const float* f0, const float* f1, const void* feat_planes, const float* flow, float* cost,
                                  void* planes_out, int ld, long plane_rows, int batch, int h, int w, int channels, int radius,
-                                 int flags, void* stream);
+                                 int flags, unsigned* stats /* optional device [2]: += tiles on the product / pixel path */,
+                                 void* stream);
 
 /* (2r+1)^2 local self-attention propagation with zero-padded keys/values (out-of-image neighbours
  * have logit 0, value 0 and take part in the softmax).

@@ -977,6 +977,7 @@ def test_cost_volume_matrix_core_path(ops, kind):
     t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
     want = hp.local_corr_with_flow(f0.double(), f1.double(), flow.double(), 4)
     assert ops._k4_feat_planes(t0, t1, h, w, 4) is not None               # the matrix-core entry point serves this geometry
+    ops.k4_adaptive = False                                               # pin that kernel (no routing by measured coherence)
     got = ops.local_corr_with_flow(t0, t1, flow.to(DEV), h, w, 4)
     scale = max(1.0, want.abs().max().item())
     assert err(got, want)[1] < 3e-6 * scale, (kind, err(got, want))
@@ -994,3 +995,51 @@ def test_cost_volume_matrix_core_path(ops, kind):
     assert (back - got).abs().max().item() < 2e-6 * scale
     assert torch.equal(pl[:, :rows, 81:], torch.zeros(2, rows, 15, device=DEV))
     assert torch.equal(pl[:, rows], torch.zeros(2, 96, device=DEV))
+    ops.k4_adaptive = True
+
+
+def test_cost_volume_adaptive_dispatch():
+    """The matrix-core cost-volume kernel reports how many tiles took its pixel-at-a-time path; HipOps reads the counters
+    without ever waiting for them and routes the following launches to the VALU kernel while the flow is mostly incoherent,
+    probing again every K4_PROBE calls.  Either kernel gives the same cost volume (to rounding)."""
+    o = HipOps('exact')
+    o.K4_PROBE = 3
+    b, h, w = 1, 32, 48
+    f0, f1 = rnd(150, b, C, h, w), rnd(151, b, C, h, w)
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    noisy = rnd(152, b, 2, h, w, scale=20.0).to(DEV)
+    smooth = torch.full((b, 2, h, w), 1.3, device=DEV)
+    want_noisy = hp.local_corr_with_flow(f0.double(), f1.double(), noisy.cpu().double(), 4)
+    want_smooth = hp.local_corr_with_flow(f0.double(), f1.double(), smooth.cpu().double(), 4)
+    assert o._k4_want_mfma()                                            # starts on the matrix-core kernel
+    for _ in range(3):
+        got = o.local_corr_with_flow(t0, t1, noisy, h, w, 4)
+        torch.cuda.synchronize()
+        assert err(got, want_noisy)[1] < 3e-6 * max(1.0, want_noisy.abs().max().item())
+    assert o._k4_state['use'] is False                                   # measured: incoherent -> VALU kernel from here on
+    used = []
+    for _ in range(8):                                                   # coherent flow now: the next probe switches back
+        used.append(o._k4_state['use'])
+        got = o.local_corr_with_flow(t0, t1, smooth, h, w, 4)
+        torch.cuda.synchronize()
+        assert err(got, want_smooth)[1] < 3e-6 * max(1.0, want_smooth.abs().max().item())
+    assert o._k4_state['use'] is True and used[0] is False
+
+
+def test_local_corr_softmax_matrix_core_path(ops):
+    """um_local_corr_softmax_mfma (matching.py:39-83 on the cost-volume kernel's product path: every tile coherent) against the
+    fp64 oracle and against the VALU kernel, incl. the image border (out-of-image taps take part with logit -1e9)."""
+    b, h, w = 2, 32, 48
+    for sc in (1.0, 3.0):                                             # soft and peaky softmaxes
+        f0, f1 = rnd(140, b, C, h, w, scale=sc), rnd(141, b, C, h, w, scale=sc)
+        f1 = 0.6 * f0.roll((1, -2), (2, 3)) + 0.4 * f1
+        t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+        want = hp.local_corr_softmax(f0.double(), f1.double(), 4)
+        assert ops.k4_mfma and ops.lib.um_local_corr_with_flow_feat_supported(h, w, C, 4)
+        got = ops.local_corr_softmax(t0, t1, h, w, 4)
+        ops.k4_mfma = False
+        try:
+            valu = ops.local_corr_softmax(t0, t1, h, w, 4)
+        finally:
+            ops.k4_mfma = True
+        assert err(got, want)[1] < 2e-5 and err(valu, want)[1] < 2e-5, (sc, err(got, want), err(valu, want))

@@ -64,7 +64,8 @@ SIGNATURES = {
     'um_local_corr_feat_planes_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'um_local_corr_feat_planes': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_local_corr_with_flow_feat_supported': (_c_int, [_c_int] * 4),
-    'um_local_corr_with_flow_feat': (_c_int, [_c_void_p] * 6 + [_c_int, ctypes.c_long] + [_c_int] * 6 + [_c_void_p]),
+    'um_local_corr_softmax_mfma': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
+    'um_local_corr_with_flow_feat': (_c_int, [_c_void_p] * 6 + [_c_int, ctypes.c_long] + [_c_int] * 6 + [_c_void_p, _c_void_p]),
     'um_prop_local_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     'um_depth_corr_softmax': (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
     'um_comm_unique_id': (_c_int, [_c_void_p]),

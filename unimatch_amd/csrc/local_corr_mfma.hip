@@ -45,6 +45,10 @@ struct K4mArgs {
     int ld;
     int batch, h, w;
     int force_valu;              // diagnostics: every tile on the VALU path
+    // local_correlation_softmax (matching.py:39-83) on the same machinery: flow == nullptr (all windows are the pixel's own
+    // 9 x 9 neighbourhood: every tile is coherent), softmax over the 81 taps, expected offset -> flow_out [B][2][h][w]
+    float* flow_out;
+    unsigned* stats;             // optional: [0] += tiles on the product path, [1] += tiles on the pixel path (adaptive dispatch)
 };
 
 __device__ __forceinline__ int k4m_wave_min(int v) {
@@ -81,18 +85,21 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
         const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
         const int x = tx * K4M_TW + (n & 7), y = ty * K4M_TH + (n >> 3);
         const int p = y * a.w + x;
-        const float px = (float)x + a.flow[((long)b * 2 + 0) * L + p];
-        const float py = (float)y + a.flow[((long)b * 2 + 1) * L + p];
+        const bool softmax_mode = a.flow_out != nullptr;                      // uniform
+        const int n1 = softmax_mode ? K4M_KW : K4M_N1;                        // integer neighbourhood: 9 x 9 (no blend) or 10 x 10
+        const float px = (float)x + (softmax_mode ? 0.f : a.flow[((long)b * 2 + 0) * L + p]);
+        const float py = (float)y + (softmax_mode ? 0.f : a.flow[((long)b * 2 + 1) * L + p]);
         const float fbx = floorf(px), fby = floorf(py);
         const float wx = px - fbx, wy = py - fby;
         // clamp far-away bases so the int conversion is defined; such samples are all-zero anyway
         const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f);
         const int by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
-        const int ux0 = k4m_wave_min(bx) - K4M_RADIUS, ux1 = k4m_wave_max(bx) - K4M_RADIUS + K4M_N1 - 1;
-        const int uy0 = k4m_wave_min(by) - K4M_RADIUS, uy1 = k4m_wave_max(by) - K4M_RADIUS + K4M_N1 - 1;
+        const int ux0 = k4m_wave_min(bx) - K4M_RADIUS, ux1 = k4m_wave_max(bx) - K4M_RADIUS + n1 - 1;
+        const int uy0 = k4m_wave_min(by) - K4M_RADIUS, uy1 = k4m_wave_max(by) - K4M_RADIUS + n1 - 1;
         const int bw = ux1 - ux0 + 1, bh = uy1 - uy0 + 1;
-        const bool coherent = !a.force_valu && bw <= 32 && bh <= K4M_MAXROWS;     // wave uniform
+        const bool coherent = softmax_mode || (!a.force_valu && bw <= 32 && bh <= K4M_MAXROWS);     // wave uniform
 
+        if (a.stats && lane == 0) atomicAdd(a.stats + (coherent ? 0 : 1), 1u);
         if (coherent) {
             // ---- B operand: the tile's 32 pixels (f0), both planes
             i16x8 qf[2][8];
@@ -130,12 +137,12 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
                     acc = Fp16::mfma(ka[0][ks], qf[0][ks], acc);               // hi_k . hi_q
                 }
                 const int iy = yy - (by - K4M_RADIUS);
-                if ((unsigned)iy < (unsigned)K4M_N1) {
+                if ((unsigned)iy < (unsigned)n1) {
                     float* d = dots + (iy * K4M_N1 + dx0) * 32 + n;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cr = (r & 3) + 8 * (r >> 2);
-                        if ((unsigned)(dx0 + cr) < (unsigned)K4M_N1) d[cr * 32] = acc[r];
+                        if ((unsigned)(dx0 + cr) < (unsigned)n1) d[cr * 32] = acc[r];
                     }
                 }
             };
@@ -151,6 +158,43 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (softmax_mode) {
+                // ---- softmax over the 81 taps and expected offset; lanes 0-31 take tap rows 0..4, lanes 32-63 rows 5..8.
+                // Out-of-image taps take part with logit -1e9 (matching.py:73)
+                const int r0 = half ? 5 : 0, r1 = half ? K4M_KW : 5;
+                float mxl = -3.0e38f;
+                for (int trow = r0; trow < r1; ++trow)
+#pragma unroll
+                    for (int tcol = 0; tcol < K4M_KW; ++tcol) {
+                        const int yy = y + trow - K4M_RADIUS, xq = x + tcol - K4M_RADIUS;
+                        const bool ok = yy >= 0 && yy < a.h && xq >= 0 && xq < a.w;
+                        const float lg = ok ? dots[(trow * K4M_N1 + tcol) * 32 + n] * scale : -1.0e9f;
+                        mxl = fmaxf(mxl, lg);
+                    }
+                mxl = fmaxf(mxl, __shfl_xor(mxl, 32));
+                float sp = 0.f, sx = 0.f, sy = 0.f;
+                for (int trow = r0; trow < r1; ++trow)
+#pragma unroll
+                    for (int tcol = 0; tcol < K4M_KW; ++tcol) {
+                        const int yy = y + trow - K4M_RADIUS, xq = x + tcol - K4M_RADIUS;
+                        const bool ok = yy >= 0 && yy < a.h && xq >= 0 && xq < a.w;
+                        const float lg = ok ? dots[(trow * K4M_N1 + tcol) * 32 + n] * scale : -1.0e9f;
+                        const float e = __expf(lg - mxl);
+                        sp += e;
+                        sx += e * (float)(tcol - K4M_RADIUS);
+                        sy += e * (float)(trow - K4M_RADIUS);
+                    }
+                sp += __shfl_xor(sp, 32);
+                sx += __shfl_xor(sx, 32);
+                sy += __shfl_xor(sy, 32);
+                if (half == 0) {
+                    a.flow_out[((long)b * 2 + 0) * L + p] = sx / sp;
+                    a.flow_out[((long)b * 2 + 1) * L + p] = sy / sp;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             // ---- blends: lanes 0-31 take tap columns 0..4, lanes 32-63 columns 5..8 of every tap row
             const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy);
             const float w10 = (1.f - wx) * wy, w11 = wx * wy;
@@ -285,10 +329,12 @@ extern "C" int um_local_corr_with_flow_feat_supported(int h, int w, int channels
 
 // Local cost volume (matching.py:86-123) with the feature planes of um_local_corr_feat_planes.  Exactly one of `cost`
 // ([B, 81, h, w] fp32) and `planes_out` (channels-last operand planes [2][plane_rows][ld], as um_local_corr_with_flow_planes)
-// is non-null.  mode bit 0: force the VALU path for every tile (diagnostics / A-B timing).
+// is non-null.  flags bit 0: force the VALU path for every tile (diagnostics / A-B timing).  stats (optional, device, 2 x
+// unsigned, caller zeroes it): tiles that took the product path / the pixel path, for a caller that wants to route launches
+// with mostly incoherent flow to um_local_corr_with_flow[_planes] (which block four pixels at a time and are ~3 % faster there).
 extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, const void* feat_planes, const float* flow, float* cost,
                                             void* planes_out, int ld, long plane_rows, int batch, int h, int w, int channels,
-                                            int radius, int flags, void* stream_) {
+                                            int radius, int flags, unsigned* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!f0 || !f1 || !feat_planes || !flow || (!cost == !planes_out) || batch <= 0) {
         um_set_error("um_local_corr_with_flow_feat: null pointer, or not exactly one output");
@@ -318,11 +364,60 @@ extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, co
     a.h = h;
     a.w = w;
     a.force_valu = flags & 1;
+    a.flow_out = nullptr;
+    a.stats = stats;
     const long ntile = rows / 32;
     long blocks = (ntile + 1) / 2;
     if (blocks > 4096) blocks = 4096;
     {
         ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
+        hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
+    }
+    return (int)hipGetLastError();
+}
+
+// local_correlation_softmax (matching.py:39-83), radius 4, 2-D, on the matrix cores: every pixel's taps are its own 9 x 9
+// neighbourhood, so every 8 x 4 tile's window is 16 x 12 and the whole map runs on the product path (the VALU kernel gathers
+// 81 x 512 B per pixel: 0.59 ms at 4 x 128 x 192).  workspace: um_local_corr_feat_planes_bytes().  out: flow [B, 2, h, w].
+extern "C" int um_local_corr_softmax_mfma(const float* f0, const float* f1, float* out, int batch, int h, int w, int channels, int radius,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!f0 || !f1 || !out || batch <= 0) {
+        um_set_error("um_local_corr_softmax_mfma: null pointer");
+        return -1;
+    }
+    if (!um_local_corr_with_flow_feat_supported(h, w, channels, radius)) {
+        um_set_error("um_local_corr_softmax_mfma: radius %d on a %dx%d map is not served (radius 4, h %% 4 == 0, w %% 8 == 0)", radius, h, w);
+        return -2;
+    }
+    if (!workspace || workspace_bytes < um_local_corr_feat_planes_bytes(batch, h, w, channels)) {
+        um_set_error("um_local_corr_softmax_mfma: workspace too small");
+        return -3;
+    }
+    if (int e = um_local_corr_feat_planes(f0, f1, workspace, batch, h, w, channels, stream_)) return e;
+    const long rows = (long)batch * h * w;
+    K4mArgs a;
+    a.f0 = f0;
+    a.f1 = f1;
+    a.fp0 = (const unsigned short*)workspace;
+    a.fp1 = (const unsigned short*)((const unsigned char*)workspace + k4m_align256(planes_bytes(rows, 0)));
+    a.plane_stride = rows * UM_CHANNELS;
+    a.flow = nullptr;
+    a.cost = nullptr;
+    a.planes = nullptr;
+    a.out_plane_stride = 0;
+    a.ld = 0;
+    a.batch = batch;
+    a.h = h;
+    a.w = w;
+    a.force_valu = 0;
+    a.flow_out = out;
+    a.stats = nullptr;
+    const long ntile = rows / 32;
+    long blocks = (ntile + 1) / 2;
+    if (blocks > 4096) blocks = 4096;
+    {
+        ScopedKernelTimer timer(UM_K_LOCAL_CORR, stream);
         hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
     }
     return (int)hipGetLastError();

@@ -463,12 +463,14 @@ class HipOps:
         _check_tokens('f0', f0, tokens=h * w)
         _check_tokens('f1', f1, b, l)
         flow = flow.contiguous()
-        feat = self._k4_feat_planes(f0, f1, h, w, radius)
+        feat = self._k4_feat_planes(f0, f1, h, w, radius) if self._k4_want_mfma() else None
         if feat is not None:
+            stats = self._k4_stats_begin(f0.device)
             code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
                 _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), None, _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius,
-                self.k4_flags, _stream()))
+                self.k4_flags, _ptr(stats), _stream()))
             _abi.check(code, 'um_local_corr_with_flow_feat')
+            self._k4_stats_end()
             return
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_planes(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius, _stream()))
@@ -476,6 +478,46 @@ class HipOps:
 
     k4_mfma = os.environ.get('UM_K4_MFMA', '1') != '0'     # cost volume on the matrix cores where the flow is coherent
     k4_flags = 1 if os.environ.get('UM_K4_FORCE_VALU') == '1' else 0
+
+    # Adaptive dispatch of the cost volume.  The matrix-core kernel is 3.6 - 7.6x faster where the flow is locally coherent (any
+    # trained model) and ~3 % slower than the VALU kernel where it is not (random-init weights; it also spends a feature split
+    # per scale).  The kernel counts the tiles that took each path; the counters come back with a non-blocking copy and are
+    # read -- never waited for -- before a later call.  Mostly incoherent: the VALU kernel serves the following calls, and
+    # every K4_PROBE-th call measures again.  UM_K4_ADAPTIVE=0 pins the matrix-core kernel.
+    K4_PROBE = 32
+    k4_adaptive = os.environ.get('UM_K4_ADAPTIVE', '1') != '0'
+
+    def _k4_want_mfma(self):
+        if not self.k4_mfma:
+            return False
+        st = self.__dict__.setdefault('_k4_state', {'use': True, 'since_probe': 0, 'event': None, 'dev': None, 'host': None})
+        if st['event'] is not None and st['event'].query():
+            coh, inc = int(st['host'][0]), int(st['host'][1])
+            st['event'] = None
+            if self.k4_adaptive and coh + inc > 0:
+                st['use'] = inc * 2 < coh + inc
+        if st['use'] or not self.k4_adaptive:
+            return True
+        st['since_probe'] += 1
+        if st['since_probe'] >= self.K4_PROBE:
+            st['since_probe'] = 0
+            return True
+        return False
+
+    def _k4_stats_begin(self, device):
+        st = self._k4_state
+        if st['dev'] is None or st['dev'].device != device:
+            st['dev'] = torch.zeros(2, dtype=torch.int32, device=device)
+            st['host'] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        return st['dev']
+
+    def _k4_stats_end(self):
+        st = self._k4_state
+        if st['event'] is None:                       # one read-back in flight at a time
+            st['host'].copy_(st['dev'], non_blocking=True)
+            st['dev'].zero_()
+            st['event'] = torch.cuda.Event()
+            st['event'].record()
 
     def _k4_feat_planes(self, f0, f1, h, w, radius):
         """fp16 hi | lo operand planes of (f0, f1) for um_local_corr_with_flow_feat, or None where that kernel does not apply.
@@ -668,6 +710,12 @@ class HipOps:
         _check_tokens('f0', f0, tokens=h * w)
         _check_tokens('f1', f1, b, l)
         out = torch.empty((b, 1 if one_d else 2, h, w), dtype=torch.float32, device=f0.device)
+        if not one_d and self.k4_mfma and self.lib.um_local_corr_with_flow_feat_supported(h, w, c, radius):
+            ws = self._ws(self.lib.um_local_corr_feat_planes_bytes(b, h, w, c), f0.device)
+            code = self._launch('local_corr_softmax', lambda: self.lib.um_local_corr_softmax_mfma(
+                _ptr(f0), _ptr(f1), _ptr(out), b, h, w, c, radius, _ptr(ws), ws.numel(), _stream()))
+            _abi.check(code, 'um_local_corr_softmax_mfma')
+            return out
         code = self._launch('local_corr_softmax', lambda: self.lib.um_local_corr_softmax(
             _ptr(f0), _ptr(f1), _ptr(out), b, h, w, c, radius, int(bool(one_d)), _stream()))
         _abi.check(code, 'um_local_corr_softmax')
@@ -683,11 +731,14 @@ class HipOps:
         k = 2 * radius + 1
         out = torch.empty((b, k * k, h, w), dtype=torch.float32, device=f0.device)
         meta = {'flops': 2.0 * b * l * (k + 1) ** 2 * c, 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l + 4.0 * k * k * b * l}
-        feat = self._k4_feat_planes(f0, f1, h, w, radius)
+        feat = self._k4_feat_planes(f0, f1, h, w, radius) if self._k4_want_mfma() else None
         if feat is not None:
+            stats = self._k4_stats_begin(f0.device)
             code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
-                _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), _ptr(out), None, 0, 0, b, h, w, c, radius, self.k4_flags, _stream()), meta)
+                _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), _ptr(out), None, 0, 0, b, h, w, c, radius, self.k4_flags,
+                _ptr(stats), _stream()), meta)
             _abi.check(code, 'um_local_corr_with_flow_feat')
+            self._k4_stats_end()
             return out
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(out), b, h, w, c, radius, _stream()), meta)
