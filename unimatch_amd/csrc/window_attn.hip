@@ -22,6 +22,7 @@
 //
 // Precision (mode): exact = fp16 hi+lo operands, 3 MFMA products per contraction (lo*hi, hi*lo, hi*hi),
 // probabilities scaled by 2^14 before the fp16 split so that small p keep 22 bits; fast = bf16, 1 product.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "planes.h"
@@ -58,6 +59,7 @@ struct WattnArgs {
     const float* beta;
     const float* residual;       // optional [S][L][128]
     float wm_scale, eps;         // 2^-wshift
+    float headroom;              // powers of two by which a moving softmax offset overshoots (exact mode: 8)
 };
 
 // window-local token -> global token index and its mask class.
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int BIAS_OFF = 2 * NS * PLANE;
     constexpr int BUF = BIAS_OFF + 4 * TK * 4;
     constexpr int PSHIFT = (NS == 2) ? 14 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    // + window-local token -> (global token << 2 | mask class), tabulated once per workgroup when the window has at most
+    // TAB_BYTES / 4 tokens (rounded up to tiles): a tile's staging arithmetic is then two LDS reads instead of ~40 VALU
+    constexpr int TAB_BYTES = 8192;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + TAB_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,6 +154,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     unsigned long long* trace_buf = g_um_trace + (size_t)(blockIdx.x / 37) * (24 * 8 + 8);
     if (tracing) trace_buf[24 * 8] = __builtin_amdgcn_s_memtime();
 #endif
+
+    const bool use_tab = ntiles * TK * 4 <= TAB_BYTES;                  // uniform
+    const unsigned* tab = reinterpret_cast<const unsigned*>(lds + 2 * BUF);
+    if (use_tab) {
+        const int ty0 = wy * a.win_h, tx0 = wx * a.win_w;
+        for (int tl = tid; tl < ntiles * TK; tl += 256) {
+            int ly = tl / a.win_w;
+            const int lx = tl - ly * a.win_w;
+            ly = min(ly, a.win_h - 1);                                  // past the window's last token: any valid row (masked)
+            const int ry = ty0 + ly, rx = tx0 + lx;
+            int oy = ry + a.shift_h, ox = rx + a.shift_w;
+            oy = oy >= a.h ? oy - a.h : oy;
+            ox = ox >= a.w ? ox - a.w : ox;
+            const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
+            reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
+        }
+        __syncthreads();
+    }
 
     // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
     // 8w..8w+7 of the tile (2 instructions per plane).  LDS chunk position cp of row r holds source chunk
@@ -200,6 +223,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned short* spk[2];
     const unsigned short* spv[2];
     auto stage_prepare = [&](int t, unsigned char* base) {
+        // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
+        const bool need = has_mask || (t + 1) * TK > a.n;
+        if (use_tab) {
+            const unsigned* tp = tab + t * TK + 8 * wave + ((lane >> 4) & 3);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long goff = (kvbase + (long)(tp[4 * j] >> 2)) * a.ldkv;
+                spk[j] = a.kp + goff + ssrc_k[j];
+                spv[j] = a.vp + goff + ssrc_v[j];
+            }
+            if (need && tid < 4 * TK) {
+                const int cq = tid >> 5, key = tid & (TK - 1);
+                const int cls = (int)(tab[t * TK + key] & 3u);
+                const float bv = t * TK + key >= a.n ? UM_NEG_MASK : ((has_mask && cls != cq) ? a.mask_raw : 0.f);
+                reinterpret_cast<float*>(base + BIAS_OFF)[cq * TK + key] = bv;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int cls;
@@ -209,8 +250,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             spk[j] = a.kp + goff + ssrc_k[j];
             spv[j] = a.vp + goff + ssrc_v[j];
         }
-        // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
-        const bool need = has_mask || (t + 1) * TK > a.n;
         if (need && tid < 4 * TK) {
             const int cq = tid >> 5, key = tid & (TK - 1);
             int cls;
@@ -220,10 +259,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         advance(bly, blx);
     };
-    auto stage_piece = [&](int i, unsigned char* base) {        // i = 0 .. NPIECE-1, compile-time after unrolling
-        const int j = i / (2 * NS), pl = (i / 2) % NS, isv = i & 1;
-        unsigned char* dst = base + (8 * wave + 4 * j) * 256 + (isv * NS + pl) * PLANE;
-        lds_dma16((isv ? spv[j] : spk[j]) + pl * a.kv_plane_stride, dst);
+    // one statement = the wave's two 4-row groups of one plane of K (or V): ONE M0 write, the second request carries the LDS
+    // (and global) displacement of 1024 bytes in its instruction offset, so its source comes in 1024 bytes low.  No M0 save /
+    // restore: hipcc keeps nothing in M0 in this kernel's loop.  4 instructions per pair instead of 10.
+    constexpr int NPAIR = 2 * NS;
+    auto stage_pair = [&](int ip, unsigned char* base) {        // ip = 0 .. NPAIR-1, compile-time after unrolling
+        const int pl = ip >> 1, isv = ip & 1;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(
+            base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
+        const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
+        const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024"
+                     : : "v"(s0), "v"(s1), "s"(dst) : "memory");
     };
 
     // per-lane LDS read offsets (loop invariant)
@@ -245,7 +292,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     stage_prepare(0, lds);
 #pragma unroll
-    for (int i = 0; i < NPIECE; ++i) stage_piece(i, lds);
+    for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -278,7 +325,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + koff[ks + 2]);
                     if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks + 2]);
                 }
-                if (staging && (ks * NPIECE) % 8 == 0) stage_piece(ks * NPIECE / 8, nxt);
+                if (staging && (ks * NPAIR) % 8 == 0) stage_pair(ks * NPAIR / 8, nxt);
                 if (NS == 2) {
                     sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
                     sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
@@ -324,12 +371,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // is allowed to lag the true running max by up to LAG: then p <= 2^(LAG + PSHIFT) = 2^15 still fits fp16,
         // and the 64-accumulator rescale -- which otherwise fires on almost every tile because SOME of the wave's
         // 32 rows moves -- becomes rare.  The branch is wave uniform; rows that did not move multiply by 1.
+        // When the offset does move it OVERSHOOTS by HEADROOM powers of two, so that the next move needs the row maximum to
+        // grow by another 2^(HEADROOM + LAG): with row maxima that creep up over the tiles (a maximum of n samples grows like
+        // sqrt(2 ln n)) SOME row moved by more than 2^LAG in most tiles.  Cost: small probabilities keep 22 bits down to
+        // 2^(-17 + HEADROOM) of the row maximum instead of 2^-17; below that the fp16 lo plane goes subnormal: absolute error
+        // 2^(-39 + HEADROOM) of the row maximum = 2^-31, far below fp32 resolution.  (UM_WATTN_HEADROOM=0: A/B timing.)
         constexpr float LAG = (NS == 2) ? 1.f : 8.f;
         const float Mn = -ceilf(m * c);
         const bool move = Mn + LAG < M;
         if (__any(move)) {
-            const float resc = move ? fast_exp2(Mn - M) : 1.f;
-            M = move ? Mn : M;
+            const float Mh = Mn - a.headroom;
+            const float resc = move ? fast_exp2(Mh - M) : 1.f;
+            M = move ? Mh : M;
             l *= resc;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -711,6 +764,8 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.total = a.nqt * a.nwin * streams;
     a.scale_log2 = UM_LOG2E / sqrtf((float)UM_CHANNELS);
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
+    static const float headroom = [] { const char* e = getenv("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
+    a.headroom = (mode == 0) ? headroom : 0.f;
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (wm) {
         if (mode == 0)
