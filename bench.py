@@ -95,11 +95,13 @@ def pmc_traffic(kernel_key, files):
 
 
 def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch):
+    from unimatch_amd.ops import HipOps
     issued = 3.0 if precision == 'exact' else 1.0
     tag = ('Fp16, 2' if precision == 'exact' else 'Bf16, 1')
     out = []
     for name, key, files, (ms, n), fl in (
-            ('window_attn_kernel', f'window_attn_kernel<{tag}, true>', ['window_attn.hip', 'common.h'], attn, flops_attn),
+            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}>",
+             ['window_attn.hip', 'common.h'], attn, flops_attn),
             ('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
              gsv, flops_gsv)):
         if not n:

@@ -116,6 +116,17 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
                              long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode,
                              void* stream);
 
+/* Same, with the query projection of unimatch/transformer.py:58 folded into the kernel's prologue:
+ *     q = x . Wq^T   for the workgroup's 128 query tokens, straight into the MFMA operand registers
+ * x: fp32 [streams*h*w][128] source tokens; wq_planes: um_weight_planes() of the query weight [128,128] with the same
+ * `wshift` as wm_planes.  A query row is consumed by exactly one workgroup, so nothing is recomputed and the q operand
+ * planes (one write + one read of [streams*h*w][128] per layer) never exist; k / v planes as above. */
+int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_planes, const void* k_planes, const void* v_planes,
+                                   const void* wm_planes, const float* gamma, const float* beta, const float* residual, float eps,
+                                   int wshift, float* out, int streams, int h, int w, int channels, int ldkv,
+                                   long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode,
+                                   void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Transformer-layer linears  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear without bias) on MFMA with fused
  * prologue / epilogue.  Replaces, per layer of unimatch/transformer.py: q/k/v projections (:58-60), merge +

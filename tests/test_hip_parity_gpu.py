@@ -869,6 +869,21 @@ def test_attention_merge_and_kv_rotate(ops, shifted, residual):
     got = ops.window_attention_merge((qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, *geom, rot, wm.to(DEV), norm,
                                      xd if residual else None)
     assert err(got.reshape(m, c), want)[0] < 5e-5
+    # the same layer with the query projection in the kernel's prologue (um_window_attn_qproj_merge_fwd)
+    got2 = ops.window_attention_qproj_merge(xd, wq.to(DEV), (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, *geom, rot, wm.to(DEV), norm,
+                                            xd if residual else None)
+    assert err(got2.reshape(m, c), want)[0] < 5e-5
+    fast = HipOps('fast')
+    kvf, _, _ = fast.linear_planes(xtd, (wk.to(DEV), wv.to(DEV)))
+    qpf, _, _ = fast.linear_planes(xd, (wq.to(DEV),))
+    ref_f = fast.window_attention_merge((qpf, m, c, 0), (kvf, m, n2, 0), (kvf, m, n2, c), s_, h, w, *geom, rot, wm.to(DEV), norm,
+                                        xd if residual else None)
+    got_f = fast.window_attention_qproj_merge(xd, wq.to(DEV), (kvf, m, n2, 0), (kvf, m, n2, c), s_, h, w, *geom, rot, wm.to(DEV),
+                                              norm, xd if residual else None)
+    # bf16 operands: q rounds the same way up to its accumulation order, so the two agree with fp64 equally well (the mean error
+    # is the stable statistic: the maximum over 2e5 LayerNorm outputs is a tail event of either evaluation)
+    e_ref, e_got = err(ref_f.reshape(m, c), want), err(got_f.reshape(m, c), want)
+    assert e_got[1] < 1.25 * e_ref[1] + 1e-4 and e_got[0] < 2.5 * e_ref[0] + 1e-3, (e_ref, e_got)
 
 
 def test_fused_layer_matches_unfused_layer(ops, golden):
@@ -886,7 +901,7 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         o0, o1 = proto(ops, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
         two = HipOps('exact')
         two.fused_ffn = False                     # the two-launch FFN stays covered
-        two.fused_merge = False                   # ... and merge + LayerNorm as its own launch
+        two.fused_merge = False                   # ... and merge + LayerNorm as its own launch (and q | k | v planes)
         t0, _ = proto(two, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
         assert err(o0, t0)[0] < 2e-4, tag
         want0, want1 = hp.feature_transformer(f0.double(), f1.double(), {kk: v.double() for kk, v in sd.items()},

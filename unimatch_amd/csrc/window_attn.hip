@@ -60,6 +60,9 @@ struct WattnArgs {
     const float* residual;       // optional [S][L][128]
     float wm_scale, eps;         // 2^-wshift
     float headroom;              // powers of two by which a moving softmax offset overshoots (exact mode: 8)
+    // QPROJ variant: q = x . Wq^T computed in the prologue (transformer.py:58); qp is unused
+    const float* x;              // [S][L][128] fp32 source tokens
+    const unsigned short* wq;    // planes [NS][128][128] of the query weight, pre-scaled by 2^wshift (stride wm_plane_stride)
 };
 
 // window-local token -> global token index and its mask class.
@@ -92,7 +95,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
                  : "memory");
 }
 
-template <class T, int NS, bool MERGE>
+template <class T, int NS, bool MERGE, bool QPROJ = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
@@ -122,32 +125,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ([f0; f1] attends [f1; f0], unimatch/transformer.py:271-291) without materialising the swapped copy
     const long kvbase = (long)((s + a.kv_rotate) % a.streams) * a.h * a.w;
 
-    // ---- this lane's query -----------------------------------------------------------------------
-    const int tq = qt * 128 + wave * 32 + (lane & 31);
-    int clsq;
-    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
-    i16x8 qf[NS][8];
-    {
-        const unsigned short* qb = a.qp + (sbase + tokq) * a.ldq + 8 * half;
+    if constexpr (QPROJ) {       // Wq -> the idle K/V ring, in flight while the token table is being built
+        const int row4 = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (8 * wave + i) + row4;
+            const int cw = pc ^ (row & 15);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.plane_stride + 16 * ks);
-        // Make hipcc retire these loads HERE: inside the tile loop its scoreboard must be empty, otherwise its
-        // counted vmcnt(N) waits for them would also wait for the (uncounted) LDS-DMA issued by inline asm.
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
+            for (int pl = 0; pl < NS; ++pl)
+                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
+        }
     }
-
-    f32x16 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
-
     const int ntiles = (a.n + TK - 1) / TK;
 #ifdef UM_TRACE
     const bool tracing = g_um_trace != nullptr && (blockIdx.x % 37) == 0 && tid == 0;
@@ -170,8 +158,115 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
             reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
         }
-        __syncthreads();
+        if (!QPROJ) __syncthreads();                                    // QPROJ: the prologue's barriers below cover it
     }
+
+    // ---- this lane's query -----------------------------------------------------------------------
+    const int tq = qt * 128 + wave * 32 + (lane & 31);
+    int clsq;
+    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
+    // per-lane LDS read offsets of an A-operand row tile (K tile, Wm / Wq rows): loop invariant
+    int koff[8];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) koff[ks] = r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
+    }
+    i16x8 qf[NS][8];
+    if constexpr (!QPROJ) {
+        const unsigned short* qb = a.qp + (sbase + tokq) * a.ldq + 8 * half;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.plane_stride + 16 * ks);
+        // Make hipcc retire these loads HERE: inside the tile loop its scoreboard must be empty, otherwise its
+        // counted vmcnt(N) waits for them would also wait for the (uncounted) LDS-DMA issued by inline asm.
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
+    } else {
+        // ---- Q^T = Wq . X^T for the workgroup's 128 queries (transformer.py:58): a query row is consumed by exactly one
+        // workgroup, so projecting it here costs no recompute (96 of the ~2400 MFMAs of a 1536-token window) and the q
+        // planes -- one write and one read of [S*L, 128] operands per layer -- never exist.  Wq rides the still idle K/V ring
+        // with the K tile's swizzle (as Wm does in the epilogue); X^T is the B operand, one token per lane, split into
+        // hi | lo in registers exactly as split_planes_kernel would; the accumulators turn into the Q^T operand
+        // fragments the way P^T does.
+        i16x8 xf[NS][8];
+        {
+            const float* xb = a.x + (sbase + tokq) * UM_CHANNELS + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(xb + 16 * ks);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + 16 * ks + 4);
+                const float y[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                u32x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hi[j] = T::pack2(y[2 * j], y[2 * j + 1]);
+                    if (NS == 2) {
+                        const f32x2 hh = T::unpack2(hi[j]);
+                        lo[j] = T::pack2(y[2 * j] - hh[0], y[2 * j + 1] - hh[1]);
+                    }
+                }
+                xf[0][ks] = __builtin_bit_cast(i16x8, hi);
+                if (NS == 2) xf[NS - 1][ks] = __builtin_bit_cast(i16x8, lo);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const i16x8 wh = *reinterpret_cast<const i16x8*>(lds + ot * (32 * 256) + koff[ks]);
+                if (NS == 2) {
+                    const i16x8 wl = *reinterpret_cast<const i16x8*>(lds + 32768 + ot * (32 * 256) + koff[ks]);
+                    acc = T::mfma(wl, xf[0][ks], acc);
+                    acc = T::mfma(wh, xf[NS - 1][ks], acc);
+                }
+                acc = T::mfma(wh, xf[0][ks], acc);
+            }
+            // lane holds, for its query, channels 32 ot + 8 g + 4 half + i (register 4 g + i): k-step 2 ot + kk of the Q^T
+            // operand = registers 8 kk .. 8 kk + 7
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                unsigned wh[4], wl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = acc[8 * kk + 2 * j] * a.wm_scale, p1 = acc[8 * kk + 2 * j + 1] * a.wm_scale;
+                    wh[j] = T::pack2(p0, p1);
+                    if (NS == 2) {
+                        const f32x2 hh = T::unpack2(wh[j]);
+                        wl[j] = T::pack2(p0 - hh[0], p1 - hh[1]);
+                    }
+                }
+                {
+                    const auto xx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
+                    const auto yy = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
+                    const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
+                    qf[0][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
+                }
+                if (NS == 2) {
+                    const auto xx = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
+                    const auto yy = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
+                    const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
+                    qf[NS - 1][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
+                }
+            }
+        }
+        __syncthreads();        // every wave is done with Wq: the ring may take tile 0
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
 
     // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
     // 8w..8w+7 of the tile (2 instructions per plane).  LDS chunk position cp of row r holds source chunk
@@ -273,13 +368,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                      : : "v"(s0), "v"(s1), "s"(dst) : "memory");
     };
 
-    // per-lane LDS read offsets (loop invariant)
-    int koff[8];
-    {
-        const int r = lane & 31;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) koff[ks] = r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
-    }
     const int li = lane & 15, lg = (lane >> 4) & 1;
     int voff[4];
     {
@@ -628,7 +716,8 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
                               int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
                               const unsigned short* wm = nullptr, const float* gamma = nullptr, const float* beta = nullptr,
-                              const float* residual = nullptr, float eps = 0.f, int wshift = 0);
+                              const float* residual = nullptr, float eps = 0.f, int wshift = 0, const float* x = nullptr,
+                              const unsigned short* wq = nullptr);
 
 static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
                                int mode) {
@@ -694,6 +783,26 @@ extern "C" int um_window_attn_merge_fwd(const void* qp, const void* kp, const vo
                               (hipStream_t)stream, (const unsigned short*)wm_planes, gamma, beta, residual, eps, wshift);
 }
 
+extern "C" int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_planes, const void* kp, const void* vp,
+                                              const void* wm_planes, const float* gamma, const float* beta, const float* residual,
+                                              float eps, int wshift, float* out, int streams, int h, int w, int channels, int ldkv,
+                                              long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate,
+                                              int mode, void* stream) {
+    if (!x || !wq_planes || !kp || !vp || !out || !wm_planes || !gamma || !beta || wshift < 0 || wshift > 14) {
+        um_set_error("um_window_attn_qproj_merge_fwd: null pointer or bad wshift");
+        return -1;
+    }
+    if (int e = check_attn_geometry(streams, h, w, channels, win_h, win_w, shift_h, shift_w, mode)) return e;
+    if (ldkv < UM_CHANNELS || ldkv % 8) {
+        um_set_error("row stride ldkv=%d must be a multiple of 8 and >= %d", ldkv, UM_CHANNELS);
+        return -1;
+    }
+    return launch_window_attn(nullptr, (const unsigned short*)kp, (const unsigned short*)vp, out, streams, h, w, UM_CHANNELS, ldkv,
+                              0, kv_plane_stride, win_h, win_w, shift_h, shift_w, kv_rotate, mode, (hipStream_t)stream,
+                              (const unsigned short*)wm_planes, gamma, beta, residual, eps, wshift, x,
+                              (const unsigned short*)wq_planes);
+}
+
 extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
     if (streams <= 0 || tokens <= 0 || channels != UM_CHANNELS || (mode != 0 && mode != 1)) return 0;
     return 3 * align256w(planes_bytes((long)streams * tokens, mode));
@@ -732,8 +841,10 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
                               int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
                               const unsigned short* wm, const float* gamma, const float* beta, const float* residual,
-                              float eps, int wshift) {
+                              float eps, int wshift, const float* x, const unsigned short* wq) {
     WattnArgs a;
+    a.x = x;
+    a.wq = wq;
     a.wm = wm;
     a.wm_plane_stride = (long)UM_CHANNELS * UM_CHANNELS;
     a.gamma = gamma;
@@ -767,7 +878,12 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     static const float headroom = [] { const char* e = getenv("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
-    if (wm) {
+    if (wm && wq) {
+        if (mode == 0)
+            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true>), dim3(a.total), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true>), dim3(a.total), dim3(256), 0, stream, a);
+    } else if (wm) {
         if (mode == 0)
             hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true>), dim3(a.total), dim3(256), 0, stream, a);
         else

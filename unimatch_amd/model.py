@@ -17,7 +17,7 @@ What is different inside:
   * inference only (the reference's training-mode extra outputs are out of scope).
   * the Transformer's linears / LayerNorm / FFN, the CNN encoder, the refinement block and the upsampler's mask head run
     on the same library (split-fp16 MFMA GEMM / implicit-GEMM convolution kernels, channels-last): on a GPU no MIOpen kernel
-    is left in the flow and stereo forwards (hipBLASLt: only the propagation layer's two small Linears with bias).
+    or hipBLASLt kernel is left in the flow and stereo forwards.
 There is no CPU or PyTorch fallback for the hot path (the stock ``nn.Module`` convolution code only runs on CPU tensors).
 """
 import math
@@ -127,6 +127,19 @@ class TransformerLayer(nn.Module):
         s, l, c = source.shape
         m = s * l
         src = source.reshape(m, c)
+        if getattr(ops, 'fused_qproj', False) and getattr(ops, 'fused_merge', False):
+            # q is projected inside the attention kernel's prologue (um_window_attn_qproj_merge_fwd): only k | v planes exist
+            kv, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
+            res = src if self.no_ffn else None
+            msg = ops.window_attention_qproj_merge(src, self.q_proj.weight, (kv, m, n2, 0), (kv, m, n2, c), s, h, w, *geom,
+                                                   kv_rotate, self.merge.weight, self.norm1, res)
+            if self.no_ffn:
+                return msg
+            msg = msg.reshape(m, c)
+            if getattr(ops, 'fused_ffn', False):
+                return ops.ffn_ln(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2).reshape(s, l, c)
+            hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)
+            return ops.linear_ln(hid, (self.mlp[2].weight,), self.norm2, residual=src, a_planes_k=nh).reshape(s, l, c)
         if target is source:                       # self attention: one projection launch for q | k | v
             qkv, _, n3 = ops.linear_planes(src, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight))
             q, k, v = (qkv, m, n3, 0), (qkv, m, n3, c), (qkv, m, n3, 2 * c)

@@ -61,6 +61,7 @@ class HipOps:
     fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
     fused_merge = os.environ.get('UM_NO_MERGE') != '1'   # merge + LayerNorm (+ residual) in the attention kernel's epilogue
+    fused_qproj = os.environ.get('UM_QPROJ', '1') == '1'   # ... and the query projection in its prologue
                                                          # (um_window_attn_merge_fwd); the env switch is for A/B timing
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
@@ -259,6 +260,29 @@ class HipOps:
             _ptr(residual) if residual is not None else None, float(norm.eps), self.WSHIFT, _ptr(out), streams, h, w, 128,
             qcols, kcols, qrows * qcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
         _abi.check(code, 'um_window_attn_merge_fwd')
+        return out
+
+    def window_attention_qproj_merge(self, x, q_weight, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate,
+                                     merge_weight, norm, residual=None):
+        """:meth:`window_attention_merge` with ``q = x . Wq^T`` computed in the kernel's prologue
+        (``um_window_attn_qproj_merge_fwd``): ``x`` fp32 ``[streams*h*w, 128]`` source tokens, ``q_weight`` ``[128, 128]``."""
+        (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = k, v
+        self._check_rows('x', x, 128)
+        if (krows, kcols) != (vrows, vcols) or x.shape[0] != streams * h * w or krows != x.shape[0]:
+            raise ValueError('inconsistent plane shapes')
+        wqp, nq, kq = self.weight_planes((q_weight,))
+        wp, n, kk = self.weight_planes((merge_weight,))
+        if (n, kk, nq, kq) != (128, 128, 128, 128):
+            raise ValueError('window_attention_qproj_merge: the query and merge weights must be [128, 128]')
+        if residual is not None:
+            self._check_rows('residual', residual, 128)
+        out = torch.empty((streams, h * w, 128), dtype=torch.float32, device=x.device)
+        meta = {'flops': 4.0 * streams * h * w * win_h * win_w * 128}
+        code = self._launch('window_attn', lambda: self.lib.um_window_attn_qproj_merge_fwd(
+            _ptr(x), _ptr(wqp), _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(wp), _ptr(norm.weight), _ptr(norm.bias),
+            _ptr(residual) if residual is not None else None, float(norm.eps), self.WSHIFT, _ptr(out), streams, h, w, 128,
+            kcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
+        _abi.check(code, 'um_window_attn_qproj_merge_fwd')
         return out
 
     # ------------------------------------------------------------------ convex upsampling (SURVEY 8(f) "next" row)
