@@ -55,62 +55,49 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 #ifndef UM_FFN_ABL
 #define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
 #endif
-// erf-GELU on two values at once, branch free (ocml's erff is two divergent branches per element: ~40 VALU slots and a
-// scheduling wall between every element).  erf: the two minimax pieces of N. Juffa's single-precision erff
-// (|a| > 0.927734375: 1 - exp(p(t)); else a + a q(a^2)), both evaluated, packed fp32 FMAs; 1.2 ulp measured against
-// fp64 over [-6, 6] (v_exp_f32 argument rounding included), i.e. gelu error < 0.6 ulp of x.
+// erf-GELU on two values at once, branch free and in ONE piece (ocml's erff is two divergent branches per element, ~40 VALU
+// slots and a scheduling wall between every element; the two-piece minimax erff this kernel used in round 1 evaluated both
+// pieces, 23 slots + v_exp_f32).  With u = |x|, h = x / 2:
+//     gelu(x) = h (1 + erf(x / sqrt 2)) = (h + |h|) - |h| erfc(u / sqrt 2),        erfc(u / sqrt 2) = 2^(u g(u))
+// g = degree-7 weighted-minimax fit of log2(erfc(u / sqrt 2)) / u on [0, 6.2] (weight = the error it causes in gelu; leading
+// coefficient negative, so 2^(u g(u)) -> 0 beyond).  erf's RELATIVE accuracy near 0 -- what the second piece of an erff buys
+// -- is not needed: gelu only sees 1 + erf.  h + |h| is exact and the final FMA rounds once, so for x < 0 the result carries
+// only v_exp_f32's relative error.  12 VALU slots per value; max error 1.03 ulp(x) against fp64 over [-12, 12] and N(0, 2)
+// samples (the two-piece form: 1.02), |error| <= 7.4e-8 |x|   (fit + evaluation script: DESIGN.md section 4).
 struct Gelu2 {
-    float x[2], a[2], t[2], s[2], r[2], q[2];      // after stage 7: x holds gelu(x)
+    float x[2], r[2];            // after the last stage: x holds gelu(x)
 };
-// One of eight stages of ~4 instructions per value (the main loop pins stages behind MFMAs).  Scalar fp32 on purpose:
+#define UM_GELU_STAGES 4
+// One of four stages of 3 instructions per value (the main loop pins stages behind MFMAs).  Scalar fp32 on purpose:
 // packed fp32 VALU issues slower beside MFMAs than the two scalar instructions it replaces (MI355X_MICROARCH.md).
 __device__ __forceinline__ void ffn_gelu_stage(Gelu2& g, int stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (UM_FFN_ABL & 1) {
-            if (stage == 7) g.x[i] = g.x[i] * 0.5f;
+            if (stage == UM_GELU_STAGES - 1) g.x[i] = g.x[i] * 0.5f;
             continue;
         }
+        const float u = __builtin_fabsf(g.x[i]);            // a source modifier, not an instruction
         switch (stage) {
         case 0:
-            g.a[i] = g.x[i] * 0.70710678118654752f;
-            g.t[i] = __builtin_fabsf(g.a[i]);
-            g.s[i] = g.a[i] * g.a[i];
+            g.r[i] = __builtin_fmaf(-2.572117637100746e-06f, u, 3.6567180359270424e-05f);
+            g.r[i] = __builtin_fmaf(g.r[i], u, -1.7448408470954746e-04f);
+            g.r[i] = __builtin_fmaf(g.r[i], u, -1.6111040895339102e-04f);
             break;
-        case 1: {
-            g.r[i] = __builtin_fmaf(-1.72853470e-5f, g.t[i], 3.83197126e-4f);
-            const float u = __builtin_fmaf(-3.88396438e-3f, g.t[i], 2.42546219e-2f);
-            g.r[i] = __builtin_fmaf(g.r[i], g.s[i], u);
-            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -1.06777877e-1f);
+        case 1:
+            g.r[i] = __builtin_fmaf(g.r[i], u, 7.089670747518539e-03f);
+            g.r[i] = __builtin_fmaf(g.r[i], u, -5.2510716021060944e-02f);
+            g.r[i] = __builtin_fmaf(g.r[i], u, -4.592045545578003e-01f);
             break;
-        }
         case 2:
-            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -6.34846687e-1f);
-            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -1.28717512e-1f);
-            g.r[i] = __builtin_fmaf(g.r[i], g.t[i], -g.t[i]);
-            g.r[i] = g.r[i] * UM_LOG2E;
-            break;
-        case 3:
+            g.r[i] = __builtin_fmaf(g.r[i], u, -1.151105523109436f);
+            g.r[i] = g.r[i] * u;
             g.r[i] = fast_exp2(g.r[i]);
-            g.q[i] = __builtin_fmaf(-5.96761703e-4f, g.s[i], 4.99119423e-3f);
-            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], -2.67681349e-2f);
-            break;
-        case 4:
-            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], 1.12819925e-1f);
-            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], -3.76125336e-1f);
-            g.q[i] = __builtin_fmaf(g.q[i], g.s[i], 1.28379166e-1f);
-            break;
-        case 5:
-            g.q[i] = __builtin_fmaf(g.q[i], g.a[i], g.a[i]);
-            g.r[i] = 1.0f - g.r[i];
-            break;
-        case 6:
-            g.r[i] = __builtin_copysignf(g.r[i], g.a[i]);
-            g.q[i] = g.t[i] > 0.927734375f ? g.r[i] : g.q[i];
             break;
         default: {
             const float hx = g.x[i] * 0.5f;
-            g.x[i] = __builtin_fmaf(hx, g.q[i], hx);
+            const float sum = hx + __builtin_fabsf(hx);
+            g.x[i] = __builtin_fmaf(-__builtin_fabsf(hx), g.r[i], sum);
             break;
         }
         }
@@ -300,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 
     // One iteration i (after barrier i):
     //     MFMA pipe :  phase B of slice i-1 (12 MFMAs, fragments built last iteration)  then  phase A of slice i+1 (24)
-    //     VALU      :  GELU of slice i (32 stages) and its H^T fragments (4 stages), pinned behind those MFMAs
+    //     VALU      :  GELU of slice i (4 x 4 stages) and its H^T fragments (4 stages), pinned behind those MFMAs
     // hipcc does not interleave the two on its own (and gives up on a sched_group_barrier pipeline of this size), so the
     // order is written out: every MFMA is followed by its share of stages and a scheduling fence.
     i16x8 pf[NS];                   // H^T fragments of the previous slice
@@ -309,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         constexpr bool HAS_B = decltype(has_b_tag)::value && !(UM_FFN_ABL & 8);
         constexpr int MF = (NS == 2) ? 3 : 1;
         constexpr int NMFMA = (HAS_A ? 8 * MF : 0) + (HAS_B ? 4 * MF : 0);
-        constexpr int NSTAGE = 36;
+        constexpr int NGELU = 4 * UM_GELU_STAGES, NSTAGE = NGELU + 4;
         const int slot = i & 1;
         const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
         const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
@@ -340,8 +327,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         auto valu_share = [&](int slot_idx) {                      // stages [slot_idx, slot_idx + 1) * NSTAGE / NMFMA
             const int upto = (slot_idx + 1) * NSTAGE / (NMFMA > 0 ? NMFMA : 1);
             for (; done < upto; ++done) {
-                if (done < 32) ffn_gelu_stage(g[done >> 3], done & 7);
-                else frag_stage(fr, g, pfn, done - 32);
+                if (done < NGELU) ffn_gelu_stage(g[done / UM_GELU_STAGES], done % UM_GELU_STAGES);
+                else frag_stage(fr, g, pfn, done - NGELU);
             }
         };
         f32x16 scn, scm;                                           // phase A alternates two accumulators (see phase B)
@@ -402,8 +389,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         for (; done < NSTAGE; ++done) {                            // whatever no MFMA was left to hide
-            if (done < 32) ffn_gelu_stage(g[done >> 3], done & 7);
-            else frag_stage(fr, g, pfn, done - 32);
+            if (done < NGELU) ffn_gelu_stage(g[done / UM_GELU_STAGES], done % UM_GELU_STAGES);
+            else frag_stage(fr, g, pfn, done - NGELU);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (decltype(has_a_tag)::value) {
