@@ -140,15 +140,27 @@ def main():
     distributed = world > 1 or os.environ.get('UM_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    gather = None
+    gather, gather_kind = None, None
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)           # "nccl" is RCCL on ROCm: launcher-side barrier / reductions
-        from unimatch_amd.dist import RcclGather
-        gather = RcclGather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))   # the data-path collective
+        from unimatch_amd.dist import RcclGather, TorchGather
+        gather_kind = 'um_allgather_preds (ncclAllGather through the C ABI, own communicator)'
+        try:
+            gather = RcclGather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))   # the data-path collective
+            ok = 1
+        except Exception as exc:                                  # noqa: BLE001 -- reported in the output line
+            gather_kind, ok = f'torch.distributed all_gather_into_tensor (um_comm_init failed: {exc})'[:240], 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # every rank must agree on the collective it uses
+        if flag.item() == 0:
+            if ok:
+                gather.close()
+                gather_kind = 'torch.distributed all_gather_into_tensor (um_comm_init failed on another rank)'
+            gather = TorchGather(rank, world, dev)
 
     from unimatch_amd import UniMatch, _abi
     from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict
@@ -237,6 +249,8 @@ def main():
     attn_flops = 4.0 * (2 * b) * L * n * c                          # QK^T + PV per launch
     if getattr(model.ops, 'fused_merge', False):
         attn_flops += 2.0 * (2 * b) * L * c * c                     # + the merge Linear folded into the epilogue
+        if getattr(model.ops, 'fused_qproj', False):
+            attn_flops += 2.0 * (2 * b) * L * c * c                 # + the query projection folded into the prologue
     gsv_flops = b * (2.0 * L * L * c + 4.0 * L * L)                 # per launch (corr or propagation)
     roof, roof2 = rooflines(attn_t, gsv_t, attn_flops, gsv_flops, args.precision, b)
 
@@ -320,7 +334,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f16x2' if args.precision == 'exact' else 'bf16',
-        'data': 'synthetic', 'rccl_ranks': rccl_ranks,
+        'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,
         'config': {'workload': f'GMFlow scale-1 flow, batch {b} x {HEIGHT}x{WIDTH} per GPU, swin K=2, global '
                                'correlation + global propagation, random-init weights',
                    'per_gpu_batch': b, 'global_batch': world * b, 'precision': args.precision,

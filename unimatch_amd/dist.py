@@ -83,6 +83,28 @@ class RcclGather:
             self.comm = ctypes.c_void_p()
 
 
+class TorchGather:
+    """Same interface on the launcher's own process group (``torch.distributed`` all-gather, RCCL underneath on GPUs):
+    what ``bench.py`` falls back to -- and says so in its output line -- when the library's communicator cannot be built."""
+
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+
+    def ranks(self):
+        return dist.get_world_size()
+
+    def all_gather(self, send, recv=None, stream=None):
+        if recv is None:
+            recv = torch.empty(self.world, *send.shape, dtype=send.dtype, device=send.device)
+        st = stream if stream is not None else torch.cuda.current_stream(send.device)
+        with torch.cuda.stream(st):
+            dist.all_gather_into_tensor(recv.view(self.world * send.shape[0], *send.shape[1:]), send)
+        return recv
+
+    def close(self):
+        pass
+
+
 _GATHER = None
 
 
