@@ -886,6 +886,34 @@ def test_attention_merge_and_kv_rotate(ops, shifted, residual):
     assert e_got[1] < 1.25 * e_ref[1] + 1e-4 and e_got[0] < 2.5 * e_ref[0] + 1e-3, (e_ref, e_got)
 
 
+@pytest.mark.parametrize('geo', [
+    (2, 16, 24, 8, 12, 4, 6, 1),        # shifted 2-D windows
+    (2, 10, 30, 1, 30, 0, 0, 0),        # 1-D row windows of 30 tokens (ragged: less than one key tile, less than a query tile)
+    (2, 12, 20, 12, 20, 0, 0, 1),       # one full window of 240 tokens (ragged last query tile and key tile)
+    (4, 6, 10, 3, 5, 1, 2, 2),          # 15-token shifted windows
+    (2, 9, 40, 1, 10, 0, 5, 1),         # shifted 1-D windows (swin-1-D)
+    (2, 64, 96, 32, 48, 16, 24, 1),     # config-2 size, shifted: token table in LDS, 48 key tiles
+    (1, 80, 120, 80, 120, 0, 0, 0),     # 9600-token full window: token table does not fit, arithmetic addressing
+])
+def test_query_projection_prologue_matches_q_planes(ops, geo):
+    """um_window_attn_qproj_merge_fwd against um_window_attn_merge_fwd fed with q planes from um_linear_fwd, over window
+    geometries (ragged tiles, shifts, 1-D windows, both addressing modes): same arithmetic up to the accumulation order of
+    q, so the two agree to fp32 rounding of the logits."""
+    s_, h, w, wh, ww, sh, sw, rot = geo
+    l, c = h * w, 128
+    m = s_ * l
+    x = rnd(900 + h, m, c, scale=1.5).to(DEV)
+    xt = rnd(901 + w, m, c, scale=1.5).to(DEV)
+    wq, wk, wv, wm = (rnd(902 + i, c, c, scale=0.09).to(DEV) for i in range(4))
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    qp, _, _ = ops.linear_planes(x, (wq,))
+    kv, _, n2 = ops.linear_planes(xt, (wk, wv))
+    ref = ops.window_attention_merge((qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, wh, ww, sh, sw, rot, wm, norm, x)
+    got = ops.window_attention_qproj_merge(x, wq, (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, wh, ww, sh, sw, rot, wm, norm, x)
+    assert torch.isfinite(got).all()
+    assert err(got, ref)[0] < 2e-5, geo
+
+
 def test_fused_layer_matches_unfused_layer(ops, golden):
     """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
     g = golden('transformer')

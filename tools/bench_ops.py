@@ -170,6 +170,16 @@ def main():
             2.0 * B * L * 81 * C, lib, iters, 'local_corr')
         run('prop local cfg4 B=4 128x192 r=1', lambda: ops.prop_local(f0, f1, flow, h, w, 1),
             2.0 * B * L * 9 * C, lib, iters, 'prop_local')
+        # config 5: plane-sweep depth correlation, 16 samples of 60x80, 64 inverse-depth candidates, a sideways camera move
+        B5, h5, w5, D = 16, 60, 80, 64
+        g0, g1 = (torch.randn(B5, h5 * w5, C, device=dev, generator=g) for _ in range(2))
+        fx = 0.9 * w5
+        K = torch.tensor([[fx, 0, w5 / 2], [0, fx, h5 / 2], [0, 0, 1.0]])
+        cam1 = torch.cat([torch.linalg.inv(K).reshape(-1), torch.eye(3).reshape(-1), torch.tensor([0.12, 0.02, 0.01]), K.reshape(-1)])
+        cam = cam1[None].repeat(B5, 1).contiguous().to(dev)
+        cand = torch.linspace(1 / 10.0, 1 / 0.5, D, device=dev)
+        run('depth corr softmax cfg5 B=16 60x80 D=64', lambda: ops.depth_corr_softmax(g0, g1, h5, w5, cam, cand),
+            2.0 * B5 * h5 * w5 * D * 4 * C, lib, iters, 'depth_corr')
 
 
 if __name__ == '__main__':

@@ -11,25 +11,29 @@
 // for the cost volume); here nothing but the [taps] logits of one pixel ever exists, in registers.
 //
 // Common structure: one wavefront per pixel, lanes = 16 tap slots x 4 channel quarters.  A lane holds 32
-// channels of f0(p) in registers, reads 128 contiguous bytes of the neighbour token (4 lanes cover the
-// 512-byte token row: coalesced), does 32 FMAs and the 4 quarter sums are combined with two DPP-class
-// shuffles.  Taps are processed 16 per round.  Softmax statistics are reduced across the 16 slots with
+// channels of f0(p) in registers (interleaved in groups of 4: see load32), reads the same channels of the
+// neighbour token in 8 loads, each of which covers 64 contiguous bytes per slot, does 32 FMAs and the 4
+// quarter sums are combined with two DPP-class shuffles.  Taps are processed 16 per round.  Softmax statistics are reduced across the 16 slots with
 // four more shuffles.  Token-major feature layout [B, L, 128] fp32.
 #include "common.h"
 #include "timing.h"
 
 #define LOCAL_MAX_ROUNDS 8      // up to 128 taps / depth candidates
 
+// A 128-channel fp32 row (512 B) is shared by the 4 lanes of a tap slot.  Lane quarter q owns channels 16 i + 4 q .. + 3
+// (i = 0..7): callers pass `row + 4 * quarter`, and load i of the four lanes covers 64 CONTIGUOUS bytes -- one request to
+// the L1 per slot and load.  (Round 1 gave each lane 32 consecutive channels: four 16-byte pieces 128 B apart per slot and
+// load, i.e. 64 cache lines touched by every wave instruction; these gather kernels were bound by exactly that.)
 __device__ __forceinline__ void load32(f32x4 (&r)[8], const float* p) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = reinterpret_cast<const f32x4*>(p)[i];
+    for (int i = 0; i < 8; ++i) r[i] = reinterpret_cast<const f32x4*>(p)[4 * i];
 }
 
 __device__ __forceinline__ float dot32(const f32x4 (&a)[8], const float* p) {
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const f32x4 b = reinterpret_cast<const f32x4*>(p)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(p)[4 * i];
         acc = __builtin_fmaf(a[i][0], b[0], acc);
         acc = __builtin_fmaf(a[i][1], b[1], acc);
         acc = __builtin_fmaf(a[i][2], b[2], acc);
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float* __
         const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
         const int y = p / w, x = p - y * w;
         f32x4 a[8];
-        load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+        load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
         float logit[LOCAL_MAX_ROUNDS];
         float mx = -3.0e38f;
 #pragma unroll
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void local_corr_softmax_kernel(const float* __
                 const bool tap = t < ntaps;
                 const bool ok = tap && yy >= 0 && yy < h && xx >= 0 && xx < w;
                 float d = 0.f;
-                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
                 d = quad_sum(d);
                 // out-of-image taps take part with logit -1e9 (matching.py:73); slots beyond ntaps do not exist
                 logit[r] = tap ? (ok ? d * scale : -1.0e9f) : -3.0e38f;
@@ -198,9 +202,9 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
             if (blocked) {
                 f32x4 a4[4][8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) load32(a4[i], f0 + (gok[i] ? p0 + j0 + i : p0 + j0) * UM_CHANNELS + 32 * quarter);
+                for (int i = 0; i < 4; ++i) load32(a4[i], f0 + (gok[i] ? p0 + j0 + i : p0 + j0) * UM_CHANNELS + 4 * quarter);
                 const int ncand = nw * nh;
-                const float* f1b = f1 + ((long)gb[0] * L) * UM_CHANNELS + 32 * quarter;
+                const float* f1b = f1 + ((long)gb[0] * L) * UM_CHANNELS + 4 * quarter;
                 for (int r = 0; r * 16 < ncand; ++r) {
                     const int t = r * 16 + slot;
                     const int cy = t / nw, cx = t - cy * nw;
@@ -258,14 +262,14 @@ __global__ __launch_bounds__(256) void local_corr_with_flow_kernel(const float* 
             const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f);
             const int by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
             f32x4 a[8];
-            load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+            load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
             for (int r = 0; r < rounds; ++r) {
                 const int t = r * 16 + slot;
                 const int iy = t / n1, ix = t - iy * n1;
                 const int yy = by + iy - radius, xx = bx + ix - radius;
                 const bool ok = t < ndots && yy >= 0 && yy < h && xx >= 0 && xx < w;
                 float d = 0.f;
-                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                if (ok) d = dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
                 d = quad_sum(d);
                 if (quarter == 0 && t < ndots) dots_s[wave][t] = d;
             }
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void prop_local_attn_kernel(const float* __res
         const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
         const int y = p / w, x = p - y * w;
         f32x4 a[8];
-        load32(a, q + pid * UM_CHANNELS + 32 * quarter);
+        load32(a, q + pid * UM_CHANNELS + 4 * quarter);
         float logit[LOCAL_MAX_ROUNDS], v0[LOCAL_MAX_ROUNDS], v1[LOCAL_MAX_ROUNDS];
         float mx = -3.0e38f;
 #pragma unroll
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void prop_local_attn_kernel(const float* __res
                 const bool ok = tap && yy >= 0 && yy < h && xx >= 0 && xx < w;
                 float d = 0.f;
                 if (ok) {
-                    d = dot32(a, k + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                    d = dot32(a, k + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
                     v0[r] = value[((long)b * vch) * L + yy * w + xx];
                     if (vch == 2) v1[r] = value[((long)b * vch + 1) * L + yy * w + xx];
                 }
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __
         const float q1 = cm[12] * r0 + cm[13] * r1 + cm[14] * r2;
         const float q2 = cm[15] * r0 + cm[16] * r1 + cm[17] * r2;
         f32x4 a[8];
-        load32(a, f0 + pid * UM_CHANNELS + 32 * quarter);
+        load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
         float logit[LOCAL_MAX_ROUNDS], cv[LOCAL_MAX_ROUNDS];
         float mx = -3.0e38f;
 #pragma unroll
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __
                             const int yy = y0 + cy, xx = x0 + cx;
                             if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
                                 const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
-                                d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 32 * quarter);
+                                d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
                             }
                         }
                 }
