@@ -220,7 +220,8 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
                 for (int j = 0; j < 5; ++j)
                     if (col0 + j < K4M_KW) outt[(trow * K4M_KW + col0 + j) * 32 + n] = res[trow][j];
         } else {
-            // ---- VALU path, one pixel at a time: lanes = 16 neighbour slots x 4 channel quarters (as local_ops.hip)
+            // ---- VALU path, one pixel at a time: lanes = 16 neighbour slots x 4 channel quarters, channels interleaved in groups
+            // of 4 so that a load covers 64 contiguous bytes per slot (as local_ops.hip)
             const int slot = lane >> 2, quarter = lane & 3;
             for (int j = 0; j < 32; ++j) {
                 const int jbx = __shfl(bx, j), jby = __shfl(by, j);
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
                 const int jp = __shfl(p, j);
                 f32x4 av[8];
                 {
-                    const float* ap = a.f0 + ((long)b * L + jp) * UM_CHANNELS + 32 * quarter;
+                    const float* ap = a.f0 + ((long)b * L + jp) * UM_CHANNELS + 4 * quarter;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) av[i] = reinterpret_cast<const f32x4*>(ap)[i];
+                    for (int i = 0; i < 8; ++i) av[i] = reinterpret_cast<const f32x4*>(ap)[4 * i];
                 }
                 for (int r = 0; r * 16 < K4M_N1 * K4M_N1; ++r) {
                     const int t = r * 16 + slot;
@@ -239,10 +240,10 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
                     const bool ok = t < K4M_N1 * K4M_N1 && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
                     float d = 0.f;
                     if (ok) {
-                        const float* bp = a.f1 + ((long)b * L + yy * a.w + xx) * UM_CHANNELS + 32 * quarter;
+                        const float* bp = a.f1 + ((long)b * L + yy * a.w + xx) * UM_CHANNELS + 4 * quarter;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const f32x4 bv = reinterpret_cast<const f32x4*>(bp)[i];
+                            const f32x4 bv = reinterpret_cast<const f32x4*>(bp)[4 * i];
                             d = __builtin_fmaf(av[i][0], bv[0], d);
                             d = __builtin_fmaf(av[i][1], bv[1], d);
                             d = __builtin_fmaf(av[i][2], bv[2], d);

@@ -10,7 +10,7 @@
 #include "common.h"
 #include "timing.h"
 
-template <int F, int V>
+template <int F, int V, bool CL = false>
 __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ mask,
                                                               float* __restrict__ up, int batch, int h, int w,
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     const long tix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= total) return;
     int x, fy, y, b;
-    if (mask_cs == 1) {
+    if (CL || mask_cs == 1) {
         // channels-last mask: the 9 F^2 logits of a pixel are contiguous, so consecutive lanes take consecutive sub-rows
         // fy of one pixel (8 lanes read 256 contiguous bytes per tap)
         fy = (int)(tix % F);
@@ -50,13 +50,23 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     // mask element (b, channel, pixel) at b * 9 F^2 L + channel * mask_cs + pixel * mask_ps  (NCHW: L, 1; NHWC: 1, 9 F^2)
     const float* mb = mask + (long)b * 9 * F * F * L + (long)fy * F * mask_cs + (long)p * mask_ps;
     float out[V][F];
+    // CL (channels-last, the layout the mask head's convolution writes): the F logits of (tap, sub-row) are contiguous -- F / 4
+    // 16-byte loads per tap, 8 lanes = the F sub-rows of a pixel cover 256 contiguous bytes (the stride-generic form below reads
+    // them one float at a time: the compiler cannot prove mask_cs == 1)
+    f32x4 lv[9][F / 4];
+    if (CL) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < F / 4; ++q) lv[k][q] = *reinterpret_cast<const f32x4*>(mb + k * F * F + 4 * q);
+    }
 #pragma unroll
     for (int fx = 0; fx < F; ++fx) {
         float lg[9];
         float mx = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            lg[k] = mb[(long)(k * F * F + fx) * mask_cs];
+            lg[k] = CL ? lv[k][fx >> 2][fx & 3] : mb[(long)(k * F * F + fx) * mask_cs];
             mx = fmaxf(mx, lg[k]);
         }
         float den = 0.f, num[V];
@@ -136,14 +146,19 @@ extern "C" int um_convex_upsample(const float* flow, const float* mask, float* u
     const float mult = is_depth ? 1.f : (float)factor;
     const long cs = mask_nhwc ? 1 : (long)h * w, ps = mask_nhwc ? 9L * factor * factor : 1;
     ScopedKernelTimer timer(UM_K_CONVEX_UPSAMPLE, stream);
-    if (factor == 8 && channels == 2)
-        hipLaunchKernelGGL((convex_upsample_kernel<8, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
-    else if (factor == 8)
-        hipLaunchKernelGGL((convex_upsample_kernel<8, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
-    else if (channels == 2)
-        hipLaunchKernelGGL((convex_upsample_kernel<4, 2>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
-    else
-        hipLaunchKernelGGL((convex_upsample_kernel<4, 1>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps);
+#define UM_UPS(F_, V_, CL_) hipLaunchKernelGGL((convex_upsample_kernel<F_, V_, CL_>), grid, block, 0, stream, flow, mask, up, batch, h, w, mult, cs, ps)
+    if (mask_nhwc) {
+        if (factor == 8 && channels == 2) UM_UPS(8, 2, true);
+        else if (factor == 8) UM_UPS(8, 1, true);
+        else if (channels == 2) UM_UPS(4, 2, true);
+        else UM_UPS(4, 1, true);
+    } else {
+        if (factor == 8 && channels == 2) UM_UPS(8, 2, false);
+        else if (factor == 8) UM_UPS(8, 1, false);
+        else if (channels == 2) UM_UPS(4, 2, false);
+        else UM_UPS(4, 1, false);
+    }
+#undef UM_UPS
     return (int)hipGetLastError();
 }
 

@@ -185,12 +185,14 @@ class FeatureTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, ops, tok0, tok1, h, w, attn_type, attn_num_splits):
-        """tok0, tok1: ``[B, h*w, C]`` token-major features (position already added)."""
-        b = tok0.shape[0]
-        stream = torch.cat([tok0, tok1], 0)            # updated stream  [f0; f1]
+    def forward(self, ops, tok0, tok1, h, w, attn_type, attn_num_splits, stream=None):
+        """tok0, tok1: ``[B, h*w, C]`` token-major features (position already added) -- or ``stream`` = the two already
+        stacked as ``[2B, h*w, C]`` (what the encoder's batched output is: no concatenation copy)."""
+        if stream is None:
+            stream = torch.cat([tok0, tok1], 0)        # updated stream  [f0; f1]
+        b = stream.shape[0] // 2
         rotate = getattr(ops, 'fused_tail', False)     # cross-attention target [f1; f0] = `prev` read with the halves rotated
-        prev = stream if rotate else torch.cat([tok1, tok0], 0)
+        prev = stream if rotate else torch.cat([stream[b:], stream[:b]], 0)
         for i, blk in enumerate(self.layers):
             shift = ('swin' in attn_type) and attn_num_splits > 1 and i % 2 == 1
             g_self = attention_windows(attn_type, True, attn_num_splits, h, w, shift)
@@ -437,10 +439,14 @@ class UniMatch(nn.Module):
             flow, pred = None, None
             for s in range(self.num_scales):
                 m0, m1 = feats[s][:nb], feats[s][nb:]                         # [B, C, h, w]
+                both = None
                 if pred_bidir_flow and s > 0:
                     m0, m1 = torch.cat([m0, m1], 0), torch.cat([m1, m0], 0)
+                    ori0, ori1 = _to_tokens(m0), _to_tokens(m1)               # pre-position, pre-warp tokens
+                else:
+                    both = _to_tokens(feats[s])                               # the encoder's batched output is [f0; f1]
+                    ori0, ori1 = both[:nb], both[nb:]
                 h, w = m0.shape[-2:]
-                ori0, ori1 = _to_tokens(m0), _to_tokens(m1)                   # pre-position, pre-warp tokens
                 up = self.upsample_factor * 2 ** (self.num_scales - 1 - s)
                 if task == 'depth':
                     k_cur = intrinsics.clone()
@@ -457,10 +463,14 @@ class UniMatch(nn.Module):
                         tok1 = _to_tokens(_warp(m1, disp))
                 splits, prop_r = attn_splits_list[s], prop_radius_list[s]
                 pos = self._position(h, w, splits, dev)
-                tok0, tok1 = ori0 + pos, tok1 + pos
                 if self.debug_taps is not None:
                     self.debug_taps[f'backbone0_s{s}'], self.debug_taps[f'backbone1_s{s}'] = m0, m1
-                tok0, tok1 = self.transformer(ops, tok0, tok1, h, w, attn_type, splits)
+                if tok1 is ori1 and both is not None:
+                    # no warp, no bidirectional stacking: the stream [f0; f1] is the encoder's output -- one position add on
+                    # the whole of it instead of two adds and a concatenation
+                    tok0, tok1 = self.transformer(ops, None, None, h, w, attn_type, splits, stream=both + pos)
+                else:
+                    tok0, tok1 = self.transformer(ops, ori0 + pos, tok1 + pos, h, w, attn_type, splits)
                 if self.debug_taps is not None:
                     self.debug_taps[f'f0_s{s}'], self.debug_taps[f'f1_s{s}'] = _to_map(tok0, h, w), _to_map(tok1, h, w)
 
