@@ -63,7 +63,7 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 // coefficient negative, so 2^(u g(u)) -> 0 beyond).  erf's RELATIVE accuracy near 0 -- what the second piece of an erff buys
 // -- is not needed: gelu only sees 1 + erf.  h + |h| is exact and the final FMA rounds once, so for x < 0 the result carries
 // only v_exp_f32's relative error.  12 VALU slots per value; max error 1.03 ulp(x) against fp64 over [-12, 12] and N(0, 2)
-// samples (the two-piece form: 1.02), |error| <= 7.4e-8 |x|   (fit + evaluation script: DESIGN.md section 4).
+// samples (the two-piece form: 1.02), |error| <= 7.4e-8 |x|   (fit + evaluation: tools/gelu_fit.py).
 struct Gelu2 {
     float x[2], r[2];            // after the last stage: x holds gelu(x)
 };
