@@ -68,7 +68,12 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;      // the n tiles of one token tile are dispatched together
+    // 1-D XCD-aware grid: the n tiles of one token tile are neighbours on ONE XCD, so the second reads the activation tile
+    // from that XCD's L2 (a 2-D grid put them on neighbouring XCDs: the k | v projection fetched its input twice from HBM,
+    // 96 MB per launch for a 50 MB tensor -- profiles/r02_pmc_fetch_v3.json)
+    const int ntn = a.N / 128;
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (wgid % ntn) * 128, m0 = (wgid / ntn) * 128;
     const int nstage = a.K / BK;
 
     // ---- staging --------------------------------------------------------------------------------------------
@@ -295,7 +300,7 @@ extern void um_set_error(const char* fmt, ...);
 
 template <int ASRC, int EPI>
 static hipError_t launch_linear(const LinArgs& a, int mode, hipStream_t stream) {
-    dim3 grid(a.N / 128, (a.M + 127) / 128), block(256);
+    dim3 grid((a.N / 128) * ((a.M + 127) / 128)), block(256);
     ScopedKernelTimer timer(UM_K_LINEAR, stream);
     if (mode == 0)
         hipLaunchKernelGGL((linear_kernel<Fp16, 2, ASRC, EPI>), grid, block, 0, stream, a);
