@@ -92,6 +92,37 @@ def test_window_attention_larger_shapes(ops, case):
     assert mx < 5e-5 * max(1.0, want.abs().max().item()), (case, mx, mean)
 
 
+def _random_window_geometries(count, seed=2024):
+    """Deterministic pseudo-random (streams, h, w, win_h, win_w, shift_h, shift_w): window sizes that are not multiples of the
+    32-key / 128-query tiles, 1-row and 1-column windows, arbitrary shifts below the window size (the kernel takes any; the
+    reference only ever uses win // 2), maps of 1 .. 4 windows per axis."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    while len(out) < count:
+        win_h, win_w = rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 12]), rng.choice([1, 3, 5, 8, 13, 17, 24, 30, 33, 40])
+        nwy, nwx = rng.choice([1, 2, 2, 3, 4]), rng.choice([1, 2, 2, 3, 4])
+        h, w = win_h * nwy, win_w * nwx
+        if h * w > 4000 or win_h * win_w > 700:
+            continue
+        sh = rng.randrange(0, win_h) if nwy > 1 and win_h > 1 and rng.random() < 0.7 else 0
+        sw = rng.randrange(0, win_w) if nwx > 1 and win_w > 1 and rng.random() < 0.7 else 0
+        out.append((rng.choice([1, 2, 3]), h, w, win_h, win_w, sh, sw))
+    return out
+
+
+@pytest.mark.parametrize('geo', _random_window_geometries(28))
+def test_window_attention_random_geometries(ops, geo):
+    """um_window_attn_fwd against the fp64 oracle over pseudo-random window geometries (see the generator)."""
+    s_, h, w, wh, ww, sh, sw = geo
+    q, k, v = (rnd(700 + i + h * w, s_, h * w, C, scale=1.5) for i in range(3))
+    want = hp.window_attention(q.double(), k.double(), v.double(), h, w, wh, ww, sh, sw)
+    got = ops.window_attention(q.to(DEV), k.to(DEV), v.to(DEV), h, w, wh, ww, sh, sw)
+    assert torch.isfinite(got).all(), geo
+    mx, mean = err(got, want)
+    assert mx < 5e-5 * max(1.0, want.abs().max().item()), (geo, mx, mean)
+
+
 def test_window_attention_forced_rescale_and_mask_dominance(ops):
     """A spiked key far down the window forces the running max to jump late (every earlier tile must be
     rescaled exactly once), and a masked key whose logit beats the own region by more than 100 must WIN the
@@ -210,6 +241,42 @@ def test_global_matching_full_size_vs_fp64(ops, ops_fast):
     assert mean < 2e-4 and mx < 5e-3, (mx, mean)
     fast = ops_fast.global_corr_softmax_flow(t0, t1, h, w)
     assert torch.isfinite(fast).all() and err(fast, want[:b])[1] < 0.5      # bf16 operands on +-150 logits: ballpark only
+
+
+def _random_matching_shapes(count, seed=77):
+    """(batch, h, w): maps whose token count is below one tile, not a multiple of 32 / 64 / 256 (ragged key and query tiles:
+    gsv_kernel and the split-KV launch), multiples of 64 at and above 512 tokens with few and with many samples
+    (gsv3_kernel / the stream-K gsv4_kernel), one-row and one-column maps."""
+    import random
+    rng = random.Random(seed)
+    out = [(1, 1, 7), (2, 9, 1), (1, 3, 10), (40, 16, 32), (3, 32, 48), (20, 24, 32)]
+    while len(out) < count:
+        h, w = rng.randrange(2, 41), rng.randrange(2, 61)
+        if h * w <= 2600:
+            out.append((rng.choice([1, 1, 2, 3, 5]), h, w))
+    return out
+
+
+@pytest.mark.parametrize('shape', _random_matching_shapes(26))
+def test_global_matching_random_shapes(ops, shape):
+    """um_global_corr_softmax_flow (one direction and both), the stereo form and um_prop_global_attn against the fp64 oracle
+    over pseudo-random map sizes (see the generator); features with real correspondences, logits to about +-40."""
+    b, h, w = shape
+    f0, f1 = rnd(400 + h, b, C, h, w, scale=2.0), rnd(401 + w, b, C, h, w, scale=2.0)
+    f1 = 0.6 * f0.roll((1, -2), (2, 3)) + 0.4 * f1
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    want = hp.global_corr_softmax_flow(f0.double(), f1.double(), True)
+    got = ops.global_corr_softmax_flow(t0, t1, h, w, bidir=True)
+    assert torch.isfinite(got).all(), shape
+    mx, mean = err(got, want)
+    assert mean < 1e-4 and mx < 2e-3, (shape, mx, mean)
+    assert err(ops.global_corr_softmax_flow(t0, t1, h, w), want[:b])[0] < 2e-3, shape
+    got_s = ops.global_corr_softmax_stereo(t0, t1, h, w)
+    assert err(got_s, hp.global_corr_softmax_stereo(f0.double(), f1.double()))[0] < 1e-3, shape
+    val = rnd(402, b, 2, h, w, scale=3.0)
+    p = torch.softmax(tok(f0).double() @ tok(f1).double().transpose(1, 2) / math.sqrt(C), -1)
+    want_p = (p @ val.double().flatten(2).transpose(1, 2)).transpose(1, 2).reshape(b, 2, h, w)
+    assert err(ops.prop_global(t0, t1, val.to(DEV), h, w), want_p)[0] < 2e-3, shape
 
 
 @pytest.mark.parametrize('b', [1, 36])           # 1 sample: gsv3_kernel (small launch); 36: gsv4_kernel (>= 8 key tiles per CU)
