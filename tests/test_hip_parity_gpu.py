@@ -417,6 +417,45 @@ def test_local_kernels_golden(ops, golden, tag):
     assert (got.cpu() - g[f'{tag}.depth_argmax']).abs().gt(1e-6).float().mean().item() < 0.01
 
 
+def _random_local_cases(count, seed=31):
+    import random
+    rng = random.Random(seed)
+    out = [(1, 1, 1, 1), (1, 2, 9, 4), (2, 9, 2, 3)]                 # one pixel; maps smaller than the window
+    while len(out) < count:
+        out.append((rng.choice([1, 2, 3]), rng.randrange(3, 34), rng.randrange(3, 50), rng.choice([1, 2, 3, 4])))
+    return out
+
+
+@pytest.mark.parametrize('case', _random_local_cases(16))
+def test_local_kernels_random_shapes(ops, case):
+    """Local correlation softmax (2-D and 1-D), the flow-displaced cost volume (fractional, exactly integer and far
+    out-of-image flow) and the plane-sweep depth correlation against the fp64 oracle over pseudo-random map sizes and
+    radii -- whichever kernel serves the shape (matrix-core or gather path)."""
+    b, h, w, r = case
+    f0, f1 = rnd(500 + h, b, C, h, w), rnd(501 + w, b, C, h, w)
+    f1 = 0.5 * f0.roll((1, 1), (2, 3)) + 0.5 * f1
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    for one_d in (False, True):
+        want = hp.local_corr_softmax(f0.double(), f1.double(), r, one_d)
+        assert err(ops.local_corr_softmax(t0, t1, h, w, r, one_d=one_d), want)[0] < 2e-4, (case, one_d)
+    flow = rnd(502, b, 2, h, w, scale=2.5)
+    flow[:, :, 0, 0] = 3.0                                              # exactly integer displacement
+    flow[:, :, -1, -1] = 1000.0                                         # far outside: all zeros
+    want = hp.local_corr_with_flow(f0.double(), f1.double(), flow.double(), r)
+    got = ops.local_corr_with_flow(t0, t1, flow.to(DEV), h, w, r)
+    assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item()), case
+    # depth: a sideways camera move, candidates that project inside and outside of the map
+    fx = 0.9 * w
+    k = torch.tensor([[fx, 0, w / 2], [0, fx, h / 2], [0, 0, 1.0]])[None].repeat(b, 1, 1)
+    pose = torch.eye(4)[None].repeat(b, 1, 1)
+    pose[:, :3, 3] = torch.tensor([0.12, -0.03, 0.02])
+    cand = torch.linspace(1 / 10.0, 1 / 0.5, 24)
+    want = hp.depth_corr_softmax(f0.double(), f1.double(), k.double(), pose.double(), cand.double())
+    cam = torch.cat([torch.inverse(k).flatten(1), pose[:, :3, :3].flatten(1), pose[:, :3, 3], k.flatten(1)], 1)
+    got = ops.depth_corr_softmax(t0, t1, h, w, cam.contiguous().to(DEV), cand.to(DEV))
+    assert err(got, want)[0] < 2e-4 * max(1.0, want.abs().max().item()), case
+
+
 def test_cost_volume_config4_size_properties(ops):
     """At config-4's scale-1 size (128x192): zero flow -> the centre tap equals the plain per-pixel
     correlation f0.f1/sqrt(C), and an integer flow only shifts which tap that is (bilinear weights 1,0,0,0)."""
