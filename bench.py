@@ -21,7 +21,8 @@ Extra objects on the line:
                         launch duration, measured with hipEvents recorded on the launch stream inside the timed region
                         (two event records per timed launch: the headline is slightly pessimistic), against the dense 16-bit
                         MFMA peak; ``traffic`` comes from a rocprofv3 PMC pass kept in profiles/ and is nulled when the
-                        kernel source has changed since that pass.
+                        kernel source has changed since that pass.  ``frac`` prices attention proper (4 L n C per stream);
+                        the merge Linear and query projection the same launch executes are in ``with_fused_linears``.
   roofline_global_corr  the same for ``gsv4_kernel`` (global correlation / propagation: the kernel the north star names).
   fast                  the bf16 throughput mode of the same workload (pairs/s, both rooflines, EPE vs fp64): reported beside
                         the headline, never as the headline and never as a parity claim.
