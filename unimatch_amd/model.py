@@ -17,7 +17,7 @@ What is different inside:
   * inference only (the reference's training-mode extra outputs are out of scope).
   * the Transformer's linears / LayerNorm / FFN, the CNN encoder, the refinement block and the upsampler's mask head run
     on the same library (split-fp16 MFMA GEMM / implicit-GEMM convolution kernels, channels-last): on a GPU no MIOpen kernel
-    or hipBLASLt kernel is left in the flow and stereo forwards.
+    or hipBLASLt kernel is left in the flow, stereo and depth forwards (rocprofv3 kernel statistics of all five configs: profiles/).
 There is no CPU or PyTorch fallback for the hot path (the stock ``nn.Module`` convolution code only runs on CPU tensors).
 """
 import math
