@@ -120,12 +120,18 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
  *     q = x . Wq^T   for the workgroup's 128 query tokens, straight into the MFMA operand registers
  * x: fp32 [streams*h*w][128] source tokens; wq_planes: um_weight_planes() of the query weight [128,128] with the same
  * `wshift` as wm_planes.  A query row is consumed by exactly one workgroup, so nothing is recomputed and the q operand
- * planes (one write + one read of [streams*h*w][128] per layer) never exist; k / v planes as above. */
+ * planes (one write + one read of [streams*h*w][128] per layer) never exist; k / v planes as above.
+ * workspace (optional, NULL = none): um_window_attn_ksplit_workspace_bytes() bytes that are ZERO before the first launch
+ * (the kernel leaves them zero; one workspace serves one launch at a time, launches on one stream are fine).  With it, a
+ * launch of few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking a whole window) gives every query tile
+ * to 2 or 4 neighbouring workgroups, each on its share of the window's keys; the first merges the others' partial softmaxes
+ * (exact).  The byte count is 0 for launches that are not split. */
+size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w);
 int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_planes, const void* k_planes, const void* v_planes,
                                    const void* wm_planes, const float* gamma, const float* beta, const float* residual, float eps,
                                    int wshift, float* out, int streams, int h, int w, int channels, int ldkv,
                                    long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode,
-                                   void* stream);
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Transformer-layer linears  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear without bias) on MFMA with fused

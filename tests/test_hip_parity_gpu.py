@@ -1000,6 +1000,11 @@ def test_attention_merge_and_kv_rotate(ops, shifted, residual):
     (2, 9, 40, 1, 10, 0, 5, 1),         # shifted 1-D windows (swin-1-D)
     (2, 64, 96, 32, 48, 16, 24, 1),     # config-2 size, shifted: token table in LDS, 48 key tiles
     (1, 80, 120, 80, 120, 0, 0, 0),     # 9600-token full window: token table does not fit, arithmetic addressing
+    # small launches: the key-split variant (2 or 4 workgroups per query tile, partial softmaxes merged through memory)
+    (1, 32, 48, 32, 48, 0, 0, 0),       # 12 query tiles x 48 key tiles: 4 parts
+    (2, 40, 56, 20, 28, 10, 14, 1),     # config-1 geometry (560-token shifted windows, ragged last key tile): 4 parts of 4.5 tiles
+    (2, 32, 48, 16, 24, 8, 12, 1),      # 384-token shifted windows, 12 key tiles: 2 parts
+    (1, 64, 96, 32, 48, 16, 24, 0),     # batch-1 config-2 geometry: 48 query tiles, 2 parts
 ])
 def test_query_projection_prologue_matches_q_planes(ops, geo):
     """um_window_attn_qproj_merge_fwd against um_window_attn_merge_fwd fed with q planes from um_linear_fwd, over window

@@ -63,6 +63,10 @@ struct WattnArgs {
     // QPROJ variant: q = x . Wq^T computed in the prologue (transformer.py:58); qp is unused
     const float* x;              // [S][L][128] fp32 source tokens
     const unsigned short* wq;    // planes [NS][128][128] of the query weight, pre-scaled by 2^wshift (stride wm_plane_stride)
+    // KSPLIT variant (small launches): `split` workgroups per query tile, each on 1 / split of the window's key tiles
+    int split;
+    float* ks_part;              // [total * (split - 1)][66][256] fp32: O^T (64 registers), M, l of the parts 1 .. split-1
+    unsigned* ks_flag;           // [total * (split - 1)], zero between launches: 1 = the slot is complete
 };
 
 // window-local token -> global token index and its mask class.
@@ -95,7 +99,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
                  : "memory");
 }
 
-template <class T, int NS, bool MERGE, bool QPROJ = false>
+template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
@@ -113,7 +117,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int wg = xcd_remap(blockIdx.x, a.total);
+    // KSPLIT: a launch with few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking the whole window) is latency-
+    // bound by that walk.  `split` workgroups share a query tile, neighbours in the grid (same XCD); part p takes the p-th
+    // share of the key tiles; parts > 0 leave (O^T, M, l) in a memory slot and raise its flag, part 0 merges them (integer
+    // offsets, power-of-two factors: exact) and runs the epilogue.  All workgroups of such a launch are resident at once
+    // (the host only splits while total * split fits), so the wait cannot deadlock.
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = KSPLIT ? a.split : 1;
+    const int wg = KSPLIT ? wgid / nsplit : wgid;
+    const int part = KSPLIT ? wgid - wg * nsplit : 0;
     const int qt = wg % a.nqt;
     const int win = (wg / a.nqt) % a.nwin;
     const int s = wg / (a.nqt * a.nwin);
@@ -137,6 +149,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     const int ntiles = (a.n + TK - 1) / TK;
+    const int t0 = KSPLIT ? (part * ntiles) / nsplit : 0;                 // this workgroup's key tiles [t0, t1)
+    const int t1 = KSPLIT ? ((part + 1) * ntiles) / nsplit : ntiles;
 #ifdef UM_TRACE
     const bool tracing = g_um_trace != nullptr && (blockIdx.x % 37) == 0 && tid == 0;
     unsigned long long* trace_buf = g_um_trace + (size_t)(blockIdx.x / 37) * (24 * 8 + 8);
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     long ssrc_k[2], ssrc_v[2];                                           // lane-constant part of the source offsets
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int row = 8 * wave + 4 * j + ((lane >> 4) & 3);
+        const int row = t0 * TK + 8 * wave + 4 * j + ((lane >> 4) & 3);     // TK is a multiple of 16: row & 15 is tile-local
         sly[j] = row / a.win_w;
         slx[j] = row - sly[j] * a.win_w;
         const int cp = lane & 15;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     int bly = 0, blx = 0;                                                // bias-table key of this thread (tid < 4*TK)
     {
-        const int key = tid & (TK - 1);
+        const int key = t0 * TK + (tid & (TK - 1));
         bly = key / a.win_w;
         blx = key - bly * a.win_w;
     }
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             voff[dt] = rowb * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
     }
 
-    stage_prepare(0, lds);
+    stage_prepare(t0, lds);
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto tile = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         UM_STAMP(0);
-        const bool staging = t + 1 < ntiles;
+        const bool staging = t + 1 < t1;
         unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
         if (staging) stage_prepare(t + 1, nxt);
         const unsigned char* kb = lds + SLOT * BUF;
@@ -562,9 +576,53 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
-    for (int t = 0; t < ntiles; t += 2) {
+    for (int t = t0; t < t1; t += 2) {
         tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if constexpr (KSPLIT) {
+        // The slots are written and read ONLY by agent-scope accesses, which go through to memory themselves; a release /
+        // acquire FENCE at agent scope would write back / invalidate the XCD's whole L2 (measured).  What is needed is the
+        // completion of the stores before the flag is raised: vmcnt(0) + the barrier.
+        if (part > 0) {
+            const long slot = (long)wg * (nsplit - 1) + part - 1;
+            float* pr = a.ks_part + slot * (66 * 256) + tid;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(pr + (dt * 16 + r) * 256, o[dt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pr + 64 * 256, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pr + 65 * 256, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        for (int p = 1; p < nsplit; ++p) {
+            const long slot = (long)wg * (nsplit - 1) + p - 1;
+            if (tid == 0) {
+                while (__hip_atomic_load(a.ks_flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+                    __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+            const float* pr = a.ks_part + slot * (66 * 256) + tid;
+            const float Mo = __hip_atomic_load(pr + 64 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float lo = __hip_atomic_load(pr + 65 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float Ms = fminf(M, Mo);                           // offsets are integers: the factors are powers of two
+            const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
+            l = l * fa + lo * fb;
+            M = Ms;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float oo = __hip_atomic_load(pr + (dt * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    o[dt][r] = o[dt][r] * fa + oo * fb;
+                }
+            __syncthreads();                                         // everybody has read the slot
+            if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+        }
     }
 
 #ifdef UM_TRACE
@@ -717,7 +775,40 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
                               const unsigned short* wm = nullptr, const float* gamma = nullptr, const float* beta = nullptr,
                               const float* residual = nullptr, float eps = 0.f, int wshift = 0, const float* x = nullptr,
-                              const unsigned short* wq = nullptr);
+                              const unsigned short* wq = nullptr, void* ks_ws = nullptr, size_t ks_ws_bytes = 0);
+
+// ---- key split for small launches (see KSPLIT in the kernel): only while every workgroup of the launch is resident at once
+static int wattn_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+static int wattn_key_split(int total, int ntiles) {
+    static const bool off = getenv("UM_WATTN_NO_KSPLIT") != nullptr;      // A/B switch
+    if (off) return 1;
+    const int cus = wattn_num_cus();
+    int split = 1;
+    // all workgroups resident at once (two per CU), at least 4 key tiles per part
+    while (split < 4 && total * (2 * split) <= 2 * cus && ntiles >= 4 * (2 * split)) split *= 2;
+    return split;
+}
+
+static size_t wattn_ks_bytes(int total, int split) {
+    const size_t slots = (size_t)total * (split - 1);
+    return align256w(slots * sizeof(unsigned)) + slots * (66 * 256 * sizeof(float));
+}
+
+extern "C" size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w) {
+    if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w) return 0;
+    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
+    const int split = wattn_key_split(total, (n + 31) / 32);
+    return split > 1 ? wattn_ks_bytes(total, split) : 0;
+}
 
 static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
                                int mode) {
@@ -787,7 +878,7 @@ extern "C" int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_pla
                                               const void* wm_planes, const float* gamma, const float* beta, const float* residual,
                                               float eps, int wshift, float* out, int streams, int h, int w, int channels, int ldkv,
                                               long kv_plane_stride, int win_h, int win_w, int shift_h, int shift_w, int kv_rotate,
-                                              int mode, void* stream) {
+                                              int mode, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !wq_planes || !kp || !vp || !out || !wm_planes || !gamma || !beta || wshift < 0 || wshift > 14) {
         um_set_error("um_window_attn_qproj_merge_fwd: null pointer or bad wshift");
         return -1;
@@ -800,7 +891,7 @@ extern "C" int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_pla
     return launch_window_attn(nullptr, (const unsigned short*)kp, (const unsigned short*)vp, out, streams, h, w, UM_CHANNELS, ldkv,
                               0, kv_plane_stride, win_h, win_w, shift_h, shift_w, kv_rotate, mode, (hipStream_t)stream,
                               (const unsigned short*)wm_planes, gamma, beta, residual, eps, wshift, x,
-                              (const unsigned short*)wq_planes);
+                              (const unsigned short*)wq_planes, workspace, workspace_bytes);
 }
 
 extern "C" size_t um_window_attn_workspace_bytes(int streams, int tokens, int channels, int mode) {
@@ -841,10 +932,13 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
                               int win_h, int win_w, int shift_h, int shift_w, int kv_rotate, int mode, hipStream_t stream,
                               const unsigned short* wm, const float* gamma, const float* beta, const float* residual,
-                              float eps, int wshift, const float* x, const unsigned short* wq) {
+                              float eps, int wshift, const float* x, const unsigned short* wq, void* ks_ws, size_t ks_ws_bytes) {
     WattnArgs a;
     a.x = x;
     a.wq = wq;
+    a.split = 1;
+    a.ks_part = nullptr;
+    a.ks_flag = nullptr;
     a.wm = wm;
     a.wm_plane_stride = (long)UM_CHANNELS * UM_CHANNELS;
     a.gamma = gamma;
@@ -877,8 +971,21 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     static const float headroom = [] { const char* e = getenv("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
+    if (wm && wq && ks_ws) {
+        const int split = wattn_key_split(a.total, (a.n + 31) / 32);
+        if (split > 1 && ks_ws_bytes >= wattn_ks_bytes(a.total, split)) {
+            a.split = split;
+            a.ks_flag = (unsigned*)ks_ws;
+            a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)a.total * (split - 1) * sizeof(unsigned)));
+        }
+    }
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
-    if (wm && wq) {
+    if (wm && wq && a.split > 1) {
+        if (mode == 0)
+            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(a.total * a.split), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, true>), dim3(a.total * a.split), dim3(256), 0, stream, a);
+    } else if (wm && wq) {
         if (mode == 0)
             hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true>), dim3(a.total), dim3(256), 0, stream, a);
         else

@@ -262,6 +262,17 @@ class HipOps:
         _abi.check(code, 'um_window_attn_merge_fwd')
         return out
 
+    def _ksplit_workspace(self, nbytes, device):
+        """The attention kernel's key-split scratch for small launches (partial softmaxes + flags): zero at allocation, left
+        zero by every launch; one buffer per device, grown on demand (launches of this object run on one stream at a time)."""
+        if not nbytes:
+            return None
+        cache = self.__dict__.setdefault('_ks_ws', {})
+        buf = cache.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = cache[device] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        return buf
+
     def window_attention_qproj_merge(self, x, q_weight, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate,
                                      merge_weight, norm, residual=None):
         """:meth:`window_attention_merge` with ``q = x . Wq^T`` computed in the kernel's prologue
@@ -278,10 +289,12 @@ class HipOps:
             self._check_rows('residual', residual, 128)
         out = torch.empty((streams, h * w, 128), dtype=torch.float32, device=x.device)
         meta = {'flops': 4.0 * streams * h * w * win_h * win_w * 128}
+        ks = self._ksplit_workspace(self.lib.um_window_attn_ksplit_workspace_bytes(streams, h, w, win_h, win_w), x.device)
         code = self._launch('window_attn', lambda: self.lib.um_window_attn_qproj_merge_fwd(
             _ptr(x), _ptr(wqp), _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(wp), _ptr(norm.weight), _ptr(norm.bias),
             _ptr(residual) if residual is not None else None, float(norm.eps), self.WSHIFT, _ptr(out), streams, h, w, 128,
-            kcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode, _stream()), meta)
+            kcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode,
+            _ptr(ks) if ks is not None else None, ks.numel() if ks is not None else 0, _stream()), meta)
         _abi.check(code, 'um_window_attn_qproj_merge_fwd')
         return out
 
