@@ -103,7 +103,7 @@ def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch, flops_attn_fus
     tag = ('Fp16, 2' if precision == 'exact' else 'Bf16, 1')
     out = []
     for name, key, files, (ms, n), fl in (
-            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}>",
+            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, false>",
              ['window_attn.hip', 'common.h'], attn, flops_attn),
             ('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
              gsv, flops_gsv)):
