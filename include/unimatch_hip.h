@@ -174,6 +174,15 @@ int um_linear_bias_fwd(const float* a0, const void* a_planes, const void* w_plan
  * through HBM).  hidden: multiple of 32, >= 64.  out: fp32 [M,128], may not alias x or y. */
 int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
                int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* stream);
+/* The same with an optional workspace of um_ffn_split_workspace_bytes(m, hidden) bytes that are ZERO before the first launch
+ * (the kernel leaves them zero; one workspace serves one launch at a time).  With it a launch of few token tiles (batch 1:
+ * 35 - 96 workgroups on 256 CUs, each walking all hidden slices) gives every tile to 2 or 4 neighbouring workgroups, each on
+ * its share of the hidden units; the first adds the others' partial outputs before LayerNorm.  The byte count is 0 for
+ * launches that are not split. */
+size_t um_ffn_split_workspace_bytes(int m, int hidden);
+int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                  int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolutions either side of the matching path, NHWC, on the matrix cores with the same

@@ -34,6 +34,9 @@ SIGNATURES = {
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),
     'um_linear_bias_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_void_p] * 2 + [_c_int, _c_void_p]),
     'um_ffn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
+    'um_ffn_ws_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_size_t,
+                                _c_void_p]),
+    'um_ffn_split_workspace_bytes': (_c_size_t, [_c_int] * 2),
     'um_conv2d_fwd': (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_void_p]),
     'um_conv2d_ex': (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p,
                               _c_int, _c_int, ctypes.c_long, _c_void_p] + [_c_int] * 13 + [_c_void_p]),

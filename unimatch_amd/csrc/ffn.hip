@@ -24,6 +24,7 @@
 // slice, which also orders the accumulator exchange.  Arithmetic: fp16 hi + lo split operands, three products,
 // fp32 accumulation (exact mode); bf16, one product (fast mode).  Weights are pre-scaled by 2^wshift.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 #include "planes.h"
 
@@ -40,6 +41,10 @@ struct FfnArgs {
     int M, hid;
     float out_scale;              // 2^-wshift
     float eps;
+    // HSPLIT variant (small launches): `split` workgroups per 128-token tile, each on 1 / split of the hidden slices
+    int split;
+    float* hs_part;               // [tiles * (split - 1)][64][256] fp32: the parts' partial O^T (already scaled)
+    unsigned* hs_flag;            // [tiles * (split - 1)], zero between launches: 1 = the slot is complete
 };
 
 __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -116,7 +121,7 @@ struct FfnLds {
     static constexpr int TOTAL = RING > 65536 ? RING : 65536;    // the epilogue overlays 4 x 16 KB of partial O
 };
 
-template <typename T, int NS>
+template <typename T, int NS, bool HSPLIT = false>
 __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     using L = FfnLds<NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -125,9 +130,19 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wave & 3, role = wave >> 2;                 // partners w, w ^ 4 sit on the same SIMD
     const int half = lane >> 5, tl = lane & 31;
-    const int m0 = blockIdx.x * 128;
+    // HSPLIT: at batch 1 the launch has 35 - 96 workgroups on 256 CUs, each walking all 32 hidden slices.  `split`
+    // neighbouring workgroups share a token tile; part p walks the p-th share of the hidden slices (the second GEMM is a sum over
+    // hidden units, so the parts' O^T simply add); parts > 0 leave their O^T in a memory slot and raise its flag, part 0 adds
+    // them and runs LayerNorm + residual.  Every workgroup of such a launch is resident at once (the host only splits while
+    // tiles * split fits the CUs), so the wait cannot deadlock.  Slots are touched by agent-scope accesses only (no
+    // agent-scope fence: those write back / invalidate the XCD's whole L2).
+    const int nsplit = HSPLIT ? a.split : 1;
+    const int tile_id = HSPLIT ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
+    const int part = HSPLIT ? (int)blockIdx.x - tile_id * nsplit : 0;
+    const int m0 = tile_id * 128;
     const int tok = m0 + 32 * pair + tl;
-    const int nslice = a.hid >> 5;
+    const int nslice = (a.hid >> 5) / nsplit;                    // slices of THIS workgroup: global slice = sbase + local
+    const int sbase = part * nslice;
 
     // ---- weight slices by LDS-DMA; the XOR swizzles are applied on the source side ---------------------------------
     // W1 slice: 16-byte chunk c (of 32) of row r sits at chunk c ^ r; one instruction moves two rows.
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         for (int i = 0; i < 2; ++i) {
             const int blk = 8 * i + wave;
             const int r = 2 * blk + half, c = tl ^ r;
-            const unsigned off = (unsigned)((((long)(32 * j + r)) * 256 + 8 * c) * 2);
+            const unsigned off = (unsigned)((((long)(32 * (sbase + j) + r)) * 256 + 8 * c) * 2);
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
                 ffn_dma16(a.w1 + pl * a.w1_plane_stride, off, lds + L::W1_OFF + slot * L::W1S + pl * L::W1P + blk * 1024);
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     // W2 slice: rows of 64 B (4 chunks), chunk c of row r at c ^ ((r >> 2) & 3); one instruction moves 16 rows.
     auto dma_w2 = [&](int j, int slot) {
         const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
-        const unsigned off = (unsigned)((((long)r) * a.hid + 32 * j + 8 * c) * 2);
+        const unsigned off = (unsigned)((((long)r) * a.hid + 32 * (sbase + j) + 8 * c) * 2);
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl)
             ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
@@ -436,15 +451,54 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                     f32x4{o[ot][4 * g], o[ot][4 * g + 1], o[ot][4 * g + 2], o[ot][4 * g + 3]};
     }
     __syncthreads();
-    if (role == 1) return;
+    if (!HSPLIT && role == 1) return;
+    if (role == 0) {
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
+        for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(ob + (4 * ot + g) * 1024);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(ob + (4 * ot + g) * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = (o[ot][4 * g + i] + r[i]) * a.out_scale;
+                for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = (o[ot][4 * g + i] + r[i]) * a.out_scale;
+            }
+    }
+    if constexpr (HSPLIT) {          // all 8 waves stay for the barriers; the role-0 waves (256 threads) carry O^T
+        const int t4 = 64 * pair + lane;
+        if (part > 0) {
+            const long slot = (long)tile_id * (nsplit - 1) + part - 1;
+            if (role == 0) {
+                float* pr = a.hs_part + slot * (64 * 256) + t4;
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __hip_atomic_store(pr + (ot * 16 + r) * 256, o[ot][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.hs_flag + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
+        for (int p = 1; p < nsplit; ++p) {
+            const long slot = (long)tile_id * (nsplit - 1) + p - 1;
+            if (tid == 0) {
+                while (__hip_atomic_load(a.hs_flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+                    __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+            if (role == 0) {
+                const float* pr = a.hs_part + slot * (64 * 256) + t4;
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        o[ot][r] += __hip_atomic_load(pr + (ot * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                       // everybody has read the slot
+            if (tid == 0) __hip_atomic_store(a.hs_flag + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+        }
+        if (role == 1) return;
+    }
     float s1 = 0.f;
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
@@ -486,23 +540,69 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
 
-template <typename T, int NS>
-static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
+template <typename T, int NS, bool HSPLIT>
+static hipError_t launch_ffn_impl(const FfnArgs& a, hipStream_t stream) {
     static bool configured = false;          // opt in to > 64 KB of LDS once per instantiation
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_kernel<T, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_kernel<T, NS, HSPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FfnLds<NS>::TOTAL);
         if (e != hipSuccess) return e;
         configured = true;
     }
     ScopedKernelTimer timer(UM_K_FFN, stream);
-    hipLaunchKernelGGL((ffn_kernel<T, NS>), dim3((a.M + 127) / 128), dim3(512), FfnLds<NS>::TOTAL, stream, a);
+    hipLaunchKernelGGL((ffn_kernel<T, NS, HSPLIT>), dim3(((a.M + 127) / 128) * a.split), dim3(512), FfnLds<NS>::TOTAL, stream, a);
     return hipGetLastError();
 }
+
+template <typename T, int NS>
+static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
+    return a.split > 1 ? launch_ffn_impl<T, NS, true>(a, stream) : launch_ffn_impl<T, NS, false>(a, stream);
+}
+
+// ---- hidden split for small launches: only while every workgroup is resident at once (one per CU: 128 KB of LDS each)
+static int ffn_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+static int ffn_hidden_split(int m, int hidden) {
+    static const bool off = getenv("UM_FFN_NO_HSPLIT") != nullptr;        // A/B switch
+    if (off) return 1;
+    const int tiles = (m + 127) / 128, nslice = hidden / 32, cus = ffn_num_cus();
+    int split = 1;
+    while (split < 4 && tiles * (2 * split) <= cus && nslice % (2 * split) == 0 && nslice / (2 * split) >= 4) split *= 2;
+    return split;
+}
+
+static size_t ffn_hs_bytes(int m, int split) {
+    const size_t slots = (size_t)((m + 127) / 128) * (split - 1);
+    return ((slots * sizeof(unsigned) + 255) & ~(size_t)255) + slots * (64 * 256 * sizeof(float));
+}
+
+extern "C" size_t um_ffn_split_workspace_bytes(int m, int hidden) {
+    if (m <= 0 || hidden < 64 || hidden % 32 != 0) return 0;
+    const int split = ffn_hidden_split(m, hidden);
+    return split > 1 ? ffn_hs_bytes(m, split) : 0;
+}
+
+extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                             int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
+                             size_t workspace_bytes, void* stream_);
 
 extern "C" int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
                           int wshift, const float* gamma, const float* beta, float eps, float* out, int mode,
                           void* stream_) {
+    return um_ffn_ws_fwd(x, y, w1_planes, w2_planes, m, hidden, wshift, gamma, beta, eps, out, mode, nullptr, 0, stream_);
+}
+
+extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                             int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
     if (!x || !y || !w1_planes || !w2_planes || !gamma || !beta || !out || m <= 0 || hidden < 64 || hidden % 32 != 0 ||
         (mode != 0 && mode != 1) || wshift < 0 || wshift > 14) {
         um_set_error("um_ffn_fwd: bad argument (m=%d hidden=%d wshift=%d mode=%d; hidden must be a multiple of 32, >= 64)",
@@ -527,6 +627,18 @@ extern "C" int um_ffn_fwd(const float* x, const float* y, const void* w1_planes,
     a.hid = hidden;
     a.out_scale = ldexpf(1.f, -wshift);
     a.eps = eps;
+    a.split = 1;
+    a.hs_part = nullptr;
+    a.hs_flag = nullptr;
+    if (workspace) {
+        const int split = ffn_hidden_split(m, hidden);
+        if (split > 1 && workspace_bytes >= ffn_hs_bytes(m, split)) {
+            const size_t slots = (size_t)((m + 127) / 128) * (split - 1);
+            a.split = split;
+            a.hs_flag = (unsigned*)workspace;
+            a.hs_part = (float*)((unsigned char*)workspace + ((slots * sizeof(unsigned) + 255) & ~(size_t)255));
+        }
+    }
     const hipError_t e = mode == 0 ? launch_ffn<Fp16, 2>(a, (hipStream_t)stream_) : launch_ffn<Bf16, 1>(a, (hipStream_t)stream_);
     if (e != hipSuccess) {
         um_set_error("um_ffn_fwd: launch failed: %s", hipGetErrorString(e));

@@ -220,10 +220,12 @@ class HipOps:
         if y.shape[0] != m:
             raise ValueError('ffn_ln: x and y must have the same number of rows')
         out = torch.empty((m, 128), dtype=torch.float32, device=x.device)
-        code = self._launch('ffn', lambda: self.lib.um_ffn_fwd(
+        ws = self._split_workspace('_ffn_ws', self.lib.um_ffn_split_workspace_bytes(m, hid), x.device)
+        code = self._launch('ffn', lambda: self.lib.um_ffn_ws_fwd(
             _ptr(x), _ptr(y), _ptr(w1p), _ptr(w2p), m, hid, self.WSHIFT, _ptr(norm.weight), _ptr(norm.bias),
-            float(norm.eps), _ptr(out), self.mode, _stream()), {'flops': 2.0 * m * hid * (256 + 128)})
-        _abi.check(code, 'um_ffn_fwd')
+            float(norm.eps), _ptr(out), self.mode, _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
+            _stream()), {'flops': 2.0 * m * hid * (256 + 128)})
+        _abi.check(code, 'um_ffn_ws_fwd')
         return out
 
     def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0, kv_rotate=0):
@@ -263,11 +265,15 @@ class HipOps:
         return out
 
     def _ksplit_workspace(self, nbytes, device):
-        """The attention kernel's key-split scratch for small launches (partial softmaxes + flags): zero at allocation, left
-        zero by every launch; one buffer per device, grown on demand (launches of this object run on one stream at a time)."""
+        return self._split_workspace('_ks_ws', nbytes, device)
+
+    def _split_workspace(self, name, nbytes, device):
+        """Scratch of a split small launch (attention: key split, FFN: hidden split -- partial results + flags): zero at
+        allocation, left zero by every launch; one buffer per kernel and device, grown on demand (launches of this object
+        run on one stream at a time)."""
         if not nbytes:
             return None
-        cache = self.__dict__.setdefault('_ks_ws', {})
+        cache = self.__dict__.setdefault(name, {})
         buf = cache.get(device)
         if buf is None or buf.numel() < nbytes:
             buf = cache[device] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
