@@ -208,6 +208,34 @@ def test_conv_statistics_bookkeeping_without_gpu():
     assert rc == -1                                                          # cin not a multiple of 32
 
 
+def test_small_launch_split_plans_without_gpu():
+    """The host-side plans of the split variants for small launches (no launch; the CU count defaults to 256 when there is no
+    device): attention splits the keys of a query tile over 2 or 4 workgroups only while all of them are resident (two per
+    CU) and each part keeps at least 4 key tiles; the FFN splits its hidden slices while tiles x parts fit the CUs (one
+    workgroup per CU).  A full-batch launch is never split: the byte count is 0."""
+    lib = _abi.load()
+    ks, hs = lib.um_window_attn_ksplit_workspace_bytes, lib.um_ffn_split_workspace_bytes
+    slot_a, slot_f = 66 * 256 * 4, 64 * 256 * 4
+
+    def ks_bytes(tiles, split):
+        return ((tiles * (split - 1) * 4 + 255) // 256) * 256 + tiles * (split - 1) * slot_a
+
+    def hs_bytes(tiles, split):
+        return ((tiles * (split - 1) * 4 + 255) // 256) * 256 + tiles * (split - 1) * slot_f
+
+    assert ks(16, 64, 96, 32, 48) == 0                           # config 2, batch 8: 768 query tiles
+    assert ks(2, 64, 96, 32, 48) == ks_bytes(96, 4)              # batch 1 at 512x768: 96 tiles x 48 key tiles -> 4 parts
+    assert ks(4, 64, 96, 32, 48) == ks_bytes(192, 2)             # batch 2: 192 tiles -> 2 parts (4 would not be resident)
+    assert ks(2, 40, 56, 20, 28) == ks_bytes(40, 4)              # config 1: 560-token windows, 18 key tiles -> 4 parts of >= 4
+    assert ks(2, 16, 24, 8, 12) == 0                             # 96-token windows: 3 key tiles, nothing to split
+    assert ks(2, 64, 96, 30, 48) == 0 and ks(0, 64, 96, 32, 48) == 0      # windows must tile the map; bad arguments
+    assert hs(16 * 6144, 1024) == 0                              # config 2, batch 8: 768 token tiles
+    assert hs(2 * 2240, 1024) == hs_bytes(35, 4)                 # config 1: 35 tiles x 32 slices -> 4 parts
+    assert hs(2 * 6144, 1024) == hs_bytes(96, 2)                 # batch 1 at 512x768: 96 tiles -> 2 parts
+    assert hs(128, 64) == 0 and hs(128, 96) == 0                 # 2 / 3 slices: too few (or not divisible) to split
+    assert hs(0, 1024) == 0 and hs(128, 1000) == 0               # bad arguments
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the GPU-less failure mode')
 def test_hot_path_fails_loudly_without_gpu():
     model, sd, i0, i1, kw, ck = build('gmflow_s1')
