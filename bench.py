@@ -157,20 +157,8 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)           # "nccl" is RCCL on ROCm: launcher-side barrier / reductions
-        from unimatch_amd.dist import RcclGather, TorchGather
-        gather_kind = 'um_allgather_preds (ncclAllGather through the C ABI, own communicator)'
-        try:
-            gather = RcclGather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))   # the data-path collective
-            ok = 1
-        except Exception as exc:                                  # noqa: BLE001 -- reported in the output line
-            gather_kind, ok = f'torch.distributed all_gather_into_tensor (um_comm_init failed: {exc})'[:240], 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # every rank must agree on the collective it uses
-        if flag.item() == 0:
-            if ok:
-                gather.close()
-                gather_kind = 'torch.distributed all_gather_into_tensor (um_comm_init failed on another rank)'
-            gather = TorchGather(rank, world, dev)
+        from unimatch_amd.dist import make_gather
+        gather, gather_kind = make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))   # the data-path collective
 
     from unimatch_amd import UniMatch, _abi
     from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict

@@ -71,6 +71,26 @@ const char* um_last_error_string(void);
 #define UM_K_FFN 10          /* ffn_kernel (um_ffn_fwd)                                                  */
 #define UM_K_CONV 11         /* conv_kernel (um_conv2d_fwd)                                              */
 #define UM_K_COUNT 12
+/* Launch census (diagnostic, off by default): with um_census_enable(1) every launch below counts the kernel INSTANTIATION that
+ * served it, so a test can assert that the configuration it checks ran the same kernels the bench times (and not, say, the
+ * small-launch split variants).  um_census_enable(1) also zeroes the counters; um_census_count(v) reads one. */
+#define UM_V_WATTN_TILE 0     /* window_attn_kernel, one workgroup per 128-query tile                                   */
+#define UM_V_WATTN_KSPLIT 1   /* window_attn_kernel<..., KSPLIT>: 2 / 4 workgroups share a query tile (small launches)  */
+#define UM_V_FFN_TILE 2       /* ffn_kernel, one workgroup per 128-token tile                                           */
+#define UM_V_FFN_HSPLIT 3     /* ffn_kernel<..., HSPLIT>: hidden slices split over 2 / 4 workgroups (small launches)    */
+#define UM_V_GSV4 4           /* gsv4_kernel (stream-K global correlation / propagation)                                */
+#define UM_V_GSV3 5           /* gsv3_kernel (causal / ragged / small launches)                                         */
+#define UM_V_K4_MFMA 6        /* k4m_kernel cost volume (matrix cores, per-tile gather path inside)                      */
+#define UM_V_K4_VALU 7        /* local_corr_with_flow_kernel cost volume (VALU)                                         */
+#define UM_V_K3_MFMA 8        /* local correlation softmax on k4m_kernel                                                */
+#define UM_V_K3_VALU 9        /* local_corr_softmax_kernel (VALU)                                                       */
+#define UM_V_CONV_PATCH 10    /* conv_patch_kernel (3x3 stride 1, 2-D halo patch)                                       */
+#define UM_V_CONV_ROWS 11     /* conv_rows_kernel (row window shared by the horizontal taps)                            */
+#define UM_V_CONV_GENERIC 12  /* conv_kernel (tap-by-tap implicit GEMM)                                                 */
+#define UM_V_COUNT 13
+int um_census_enable(int on);
+long um_census_count(int variant);
+
 /* Diagnostic: a memory-free loop of independent 32x32x16 fp16 MFMAs on every CU (8 * iters MFMAs per wave, 1024 workgroups of
  * 8 waves): the sustained matrix-pipe rate of this part under its power limit, with one constant operand value or with
  * pseudo-random operands (data toggling costs clock).  sink: any device float. */
@@ -401,7 +421,9 @@ int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long p
  *                       (torch.distributed store, MPI, a file);
  *   um_comm_init_rank   every rank: ncclCommInitRank on the calling thread's current HIP device;
  *   um_comm_init_file   both steps through a file on a filesystem all ranks see: rank 0 publishes `path` atomically, the
- *                       others poll for it up to timeout_seconds (< 0: forever).  The caller chooses a job-unique path.
+ *                       others poll for it up to timeout_seconds (< 0: forever).  The caller chooses a job-unique path; rank 0
+ *                       removes a leftover at `path` first, the record carries the world size and a wall-clock stamp (records
+ *                       older than 10 minutes are ignored) and rank 0 deletes it once every rank has joined.
  *   um_allgather_preds  ncclAllGather(send, recv, count_per_rank floats) enqueued on `stream` (the caller's compute or side
  *                       stream; no host synchronisation).  recv: [world][count_per_rank], rank major.
  *   um_comm_world       number of ranks of the communicator (ncclCommCount);  um_comm_destroy releases it.
@@ -415,6 +437,33 @@ int um_comm_init_file(void** comm_out, const char* path, int rank, int world, in
 int um_comm_world(void* comm);
 int um_comm_destroy(void* comm);
 int um_allgather_preds(void* comm, const float* send, float* recv, size_t count_per_rank, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SURVEY.md 8(b) names.  The survey's contract lists um_<op> / um_workspace_bytes_<op>; where this header spells an
+ * entry point differently the literal name is exported too (csrc/aliases.hip, thin forwards):
+ *   um_swin_attn_fwd          = um_window_attn_fwd                             (attention.py:8-16, 45-104)
+ *   um_attn1d_fwd             = um_window_attn_fwd with win_h = 1, shift_h = 0 (attention.py:19-42, 107-163)
+ *   um_local_corr_softmax_1d  = um_local_corr_softmax with one_d = 1           (matching.py:154-200)
+ *   um_workspace_bytes_<op>(batch_or_streams, h, w, channels, mode)            (0 where um_<op> takes no workspace)
+ * ------------------------------------------------------------------------------------------- */
+int um_swin_attn_fwd(const float* q, const float* k, const float* v, float* out, int streams, int h, int w, int channels,
+                     int win_h, int win_w, int shift_h, int shift_w, int mode, void* workspace, size_t workspace_bytes,
+                     void* stream);
+int um_attn1d_fwd(const float* q, const float* k, const float* v, float* out, int streams, int h, int w, int channels,
+                  int win_w, int shift_w, int mode, void* workspace, size_t workspace_bytes, void* stream);
+int um_local_corr_softmax_1d(const float* f0, const float* f1, float* out, int batch, int h, int w, int channels, int radius,
+                             void* stream);
+size_t um_workspace_bytes_swin_attn_fwd(int streams, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_attn1d_fwd(int streams, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_global_corr_softmax_flow(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_global_corr_softmax_stereo(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_prop_global_attn(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_local_corr_softmax(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_local_corr_softmax_1d(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_local_corr_with_flow(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_prop_local_attn(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_depth_corr_softmax(int batch, int h, int w, int channels, int mode);
+size_t um_workspace_bytes_allgather_preds(int batch, int h, int w, int channels, int mode);
 
 #ifdef __cplusplus
 }

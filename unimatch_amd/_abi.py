@@ -12,6 +12,10 @@ LIB_PATH = os.environ.get('UM_LIB') or os.path.join(_HERE, 'libunimatch_hip.so')
 MODE_EXACT = 0
 MODE_FAST = 1
 
+# launch census ids (UM_V_* of the header): which kernel instantiation served a call
+CENSUS = {'wattn_tile': 0, 'wattn_ksplit': 1, 'ffn_tile': 2, 'ffn_hsplit': 3, 'gsv4': 4, 'gsv3': 5, 'k4_mfma': 6, 'k4_valu': 7,
+          'k3_mfma': 8, 'k3_valu': 9, 'conv_patch': 10, 'conv_rows': 11, 'conv_generic': 12}
+
 _c_int, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 
 # name -> (restype, argtypes); mirrors include/unimatch_hip.h one to one
@@ -74,6 +78,15 @@ SIGNATURES = {
     'um_local_corr_with_flow_feat': (_c_int, [_c_void_p] * 6 + [_c_int, ctypes.c_long] + [_c_int] * 6 + [_c_void_p, _c_void_p]),
     'um_prop_local_attn': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     'um_depth_corr_softmax': (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
+    'um_census_enable': (_c_int, [_c_int]),
+    'um_census_count': (ctypes.c_long, [_c_int]),
+    'um_swin_attn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_attn1d_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p, _c_size_t, _c_void_p]),
+    'um_local_corr_softmax_1d': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
+    **{f'um_workspace_bytes_{op}': (_c_size_t, [_c_int] * 5) for op in (
+        'swin_attn_fwd', 'attn1d_fwd', 'global_corr_softmax_flow', 'global_corr_softmax_stereo', 'prop_global_attn',
+        'local_corr_softmax', 'local_corr_softmax_1d', 'local_corr_with_flow', 'prop_local_attn', 'depth_corr_softmax',
+        'allgather_preds')},
     'um_comm_unique_id': (_c_int, [_c_void_p]),
     'um_comm_init_rank': (_c_int, [ctypes.POINTER(_c_void_p), _c_void_p, _c_int, _c_int]),
     'um_comm_init_file': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_char_p, _c_int, _c_int, _c_int]),
@@ -112,6 +125,12 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def census(lib=None):
+    """Launch counts since the last ``um_census_enable(1)`` as ``{name: count}``."""
+    lib = lib or load()
+    return {k: int(lib.um_census_count(v)) for k, v in CENSUS.items()}
 
 
 def check(code, what):

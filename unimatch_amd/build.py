@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libunimatch_hip.so')
 SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip', 'microbench.hip',
-           'rccl_gather.hip', 'local_corr_mfma.hip']
+           'rccl_gather.hip', 'local_corr_mfma.hip', 'aliases.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
 # per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
 EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize']}

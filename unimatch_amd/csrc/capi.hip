@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -87,4 +88,28 @@ extern "C" int um_timing_collect(int kernel_id, double* total_ms, int* launches)
     *total_ms = sum;
     *launches = n;
     return 0;
+}
+
+// ---- launch census: which instantiation served each call (tests assert the measured configuration ran the kernels the
+// bench times: non-split attention / FFN, gsv4; see UM_V_* in the header).  Off by default; relaxed counters, no ordering.
+namespace {
+std::atomic<int> g_census_on{0};
+std::atomic<long> g_census[UM_V_COUNT];
+}  // namespace
+
+void um_census_hit(int variant) {
+    if (variant >= 0 && variant < UM_V_COUNT && g_census_on.load(std::memory_order_relaxed))
+        g_census[variant].fetch_add(1, std::memory_order_relaxed);
+}
+
+extern "C" int um_census_enable(int on) {
+    g_census_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    if (on)
+        for (auto& c : g_census) c.store(0, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" long um_census_count(int variant) {
+    if (variant < 0 || variant >= UM_V_COUNT) return -1;
+    return g_census[variant].load(std::memory_order_relaxed);
 }

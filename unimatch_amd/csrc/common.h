@@ -3,6 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// A/B switches for same-box timing runs exist ONLY in diagnostic builds (-DUM_DEBUG_SWITCHES, `python -m unimatch_amd.build
+// --variant NAME -DUM_DEBUG_SWITCHES ...` -> unimatch_amd/_variants/libNAME.so, loaded through UM_LIB): the shipped library never
+// reads the environment, its behaviour is a pure function of the arguments of each call.
+#ifdef UM_DEBUG_SWITCHES
+#include <stdlib.h>
+static inline const char* um_debug_env(const char* name) { return getenv(name); }
+#else
+static inline const char* um_debug_env(const char*) { return nullptr; }
+#endif
+
+// CUs of the calling thread's CURRENT device (the launch plans that need "every workgroup resident at once" are sized by it):
+// looked up per device and remembered; 256 when there is no device (host-side plan queries on a GPU-less box).
+static inline int um_num_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < 64 && cache[dev] > 0) return cache[dev];
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    if (dev < 64) cache[dev] = v;      // racing writers store the same value
+    return v;
+}
+
 #define UM_CHANNELS 128          // feature channels of every UniMatch variant (unimatch/unimatch.py:19)
 #define UM_WAVE 64
 

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_patch_kernel(ConvA
 extern void um_set_error(const char* fmt, ...);
 
 static int conv_xcd_enabled() {
-    static const int on = getenv("UM_CONV_NO_XCD") == nullptr;     // A/B switch (tools/ab_bench.py), read once
+    static const int on = um_debug_env("UM_CONV_NO_XCD") == nullptr;     // A/B switch (tools/ab_bench.py), read once
     return on;
 }
 
@@ -792,6 +792,7 @@ template <int NT>
 static hipError_t launch_conv(const ConvArgs& a, int mode, hipStream_t stream) {
     dim3 grid(a.B * ((a.Ho * a.Wo + 127) / 128) * ((a.Cout + 32 * NT - 1) / (32 * NT))), block(256);
     ScopedKernelTimer timer(UM_K_CONV, stream);
+    um_census_hit(UM_V_CONV_GENERIC);
     if (mode == 0)
         hipLaunchKernelGGL((conv_kernel<Fp16, 2, NT>), grid, block, 0, stream, a);
     else
@@ -806,6 +807,7 @@ static hipError_t launch_conv_rows(const ConvArgs& a, int mode, hipStream_t stre
     constexpr int LDS2 = ConvRowsLds<2, NT, KW, NSLOT>::TOTAL, LDS1 = ConvRowsLds<1, NT, KW, NSLOT>::TOTAL;
     static_assert(LDS2 <= 160 * 1024 && LDS1 <= 160 * 1024, "ring beyond the CU's LDS");
     ScopedKernelTimer timer(UM_K_CONV, stream);
+    um_census_hit(UM_V_CONV_ROWS);
     if (mode == 0) {
         if (!configured[0]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<Fp16, 2, NT, KW, NSLOT>),
@@ -833,6 +835,7 @@ static hipError_t launch_conv_patch(const ConvArgs& a, int mode, hipStream_t str
     constexpr int LDS2 = ConvPatchLds<2, NT>::TOTAL, LDS1 = ConvPatchLds<1, NT>::TOTAL;
     static_assert(LDS2 <= 160 * 1024 && LDS1 <= 160 * 1024, "ring beyond the CU's LDS");
     ScopedKernelTimer timer(UM_K_CONV, stream);
+    um_census_hit(UM_V_CONV_PATCH);
     if (mode == 0) {
         if (!configured[0]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Fp16, 2, NT>),
@@ -862,8 +865,8 @@ static ConvKind conv_pick(int hi, int wi, int ho, int wo, int cout, int kh, int 
     *nt_out = nt;
     // A/B switches (tools/ab_bench.py), read once: UM_CONV_NO_ROWS = generic kernel only; UM_CONV_PATCH = the tile widths
     // (digits of NT) the 2-D patch kernel may serve
-    static const bool rows_enabled = getenv("UM_CONV_NO_ROWS") == nullptr;
-    static const char* patch_env = getenv("UM_CONV_PATCH");
+    static const bool rows_enabled = um_debug_env("UM_CONV_NO_ROWS") == nullptr;
+    static const char* patch_env = um_debug_env("UM_CONV_PATCH");
     static const char* patch_nts = patch_env ? patch_env : "234";
     // same-size stride-1 rows of 3 taps (any tile width) or 5 taps (128-wide tiles: the GRU's 1x5 gates): row-window kernel
     const bool same = stride == 1 && ho == hi && wo == wi && (long)ho * wo >= 256 && rows_enabled;

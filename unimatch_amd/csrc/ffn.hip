@@ -550,6 +550,7 @@ static hipError_t launch_ffn_impl(const FfnArgs& a, hipStream_t stream) {
         configured = true;
     }
     ScopedKernelTimer timer(UM_K_FFN, stream);
+    um_census_hit(HSPLIT ? UM_V_FFN_HSPLIT : UM_V_FFN_TILE);
     hipLaunchKernelGGL((ffn_kernel<T, NS, HSPLIT>), dim3(((a.M + 127) / 128) * a.split), dim3(512), FfnLds<NS>::TOTAL, stream, a);
     return hipGetLastError();
 }
@@ -560,18 +561,10 @@ static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
 }
 
 // ---- hidden split for small launches: only while every workgroup is resident at once (one per CU: 128 KB of LDS each)
-static int ffn_num_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return n;
-}
+static int ffn_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 static int ffn_hidden_split(int m, int hidden) {
-    static const bool off = getenv("UM_FFN_NO_HSPLIT") != nullptr;        // A/B switch
+    static const bool off = um_debug_env("UM_FFN_NO_HSPLIT") != nullptr;        // A/B switch
     if (off) return 1;
     const int tiles = (m + 127) / 128, nslice = hidden / 32, cus = ffn_num_cus();
     int split = 1;

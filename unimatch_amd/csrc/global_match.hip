@@ -11,12 +11,15 @@
 // evaluated blockwise with a running (max, sum, sum*v) per query, and because v has only 1-2 channels
 // the "P.V" product is a few fp32 FMAs per score instead of a second matmul.
 //
-// Work decomposition: workgroup = 4 waves = 128 queries; wave = 32 queries; key tiles of 64.
+// Two kernels:
+//   gsv4_kernel  non-causal launches whose key count is whole 64-key tiles and that fill the chip (flow, propagation at the
+//                BASELINE sizes): one wave per SIMD, 64 queries per wave, Q fragments in AGPRs, stream-K over the chip;
+//   gsv3_kernel  everything else -- the causal per-scanline stereo layer, ragged key counts, small launches: workgroup =
+//                4 waves = 128 queries, wave = 32 queries, key tiles of 64, software-pipelined at instruction level.
 // Scores are computed "swapped", S^T = K . Q^T with v_mfma_f32_32x32x16, so lane l owns query (l & 31)
 // and holds 16 of the 32 key scores of a sub-tile; lanes l and l^32 split the keys of a query between
 // them and keep INDEPENDENT running maxima, merged once at the end (no cross-lane traffic per tile).
-// K tiles are staged through LDS (rows padded to 272 B: conflict-free ds_read_b128 A-fragments) with
-// the next tile's global loads in flight during the current tile's MFMAs.
+// (Round 1's phase-structured gsv_kernel was retired in round 3; profiles/r02_gsv4_v1_ab.txt has its last A/B.)
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -61,227 +64,10 @@ __device__ __forceinline__ void gsv_dma4(const void* base, unsigned byte_off, co
                  : "memory");
 }
 
-template <class T, int NS, int NV, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void gsv_kernel(GsvArgs a) {
-    // LDS ring, two slots of one 64-key tile each: K planes as linear 256-byte rows whose 16-byte chunks are
-    // XOR-swizzled by (row & 15) through the SOURCE address (LDS-DMA writes lane-linear; ds_read_b128 A fragments
-    // then are conflict free), followed by the tile's values [NV][64] fp32.  Tile t+1 streams in by LDS-DMA while
-    // tile t is consumed; one barrier per tile.
-    constexpr int TK = 64;
-    constexpr int PLANE = TK * 256;
-    constexpr int VOFF = NS * PLANE;
-    constexpr int SLOT = VOFF + NV * TK * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5;
-    const int b = blockIdx.y;
-    const int qwg = blockIdx.x * 128;
-    const int qi = qwg + wave * 32 + (lane & 31);
-    const float c = a.scale_log2;
-
-    // ---- Q fragments: B operand of S^T = K . Q^T -------------------------------------------
-    i16x8 qf[NS][8];
-    {
-        const int qr = min(qi, a.Lq - 1);
-        const unsigned short* qb = a.qp + ((long)b * a.Lq + qr) * UM_CHANNELS + 8 * half;
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qf[pl][ks] = ld_global_16B(qb + pl * a.q_plane_stride + 16 * ks);
-        // retire these loads before the loop: inside it hipcc's vmcnt scoreboard must stay empty (hidden DMA)
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[pl][ks]));
-    }
-
-    int ntiles = (a.Lk + TK - 1) / TK;
-    if (CAUSAL) ntiles = min(ntiles, (min(qwg + 127, a.Lq - 1) / TK) + 1);
-    // split-KV: this workgroup owns key tiles [tbeg, tend)
-    const int per = (ntiles + a.nsplit - 1) / a.nsplit;
-    const int tbeg = blockIdx.z * per, tend = min(ntiles, tbeg + per);
-
-    // ---- staging: wave w moves rows 16w .. 16w+15 of a tile, 4 rows (64 lanes x 16 B) per DMA instruction ----
-    const unsigned kbase_bytes = (unsigned)((long)b * a.Lk * UM_CHANNELS * 2);
-    const int srow = 16 * wave + (lane >> 4);                    // + 4 * j
-    const int scp = lane & 15;
-    constexpr int NPIECE = 4 * NS;                               // K pieces per wave per tile
-    auto k_piece = [&](int t, int i, unsigned char* slot) {     // i = 0 .. NPIECE-1
-        const int j = i / NS, pl = i % NS;
-        const int row = srow + 4 * j;
-        const int key = min(t * TK + row, a.Lk - 1);
-        const unsigned off = kbase_bytes + (unsigned)key * (UM_CHANNELS * 2) + ((scp ^ (row & 15)) << 4);
-        gsv_dma16(a.kp + pl * a.k_plane_stride, off, slot + pl * PLANE + (16 * wave + 4 * j) * 256);
-    };
-    const float* vbase = a.v + (long)b * a.v_batch_stride;
-    auto v_piece = [&](int t, unsigned char* slot) {             // wave ch stages channel ch (64 lanes x 4 B)
-        if (wave < NV) {
-            const int key = min(t * TK + lane, a.Lk - 1);
-            gsv_dma4(vbase + wave * a.v_chan_stride, (unsigned)key * 4, slot + VOFF + wave * TK * 4);
-        }
-    };
-
-    // Running softmax state.  m = running max of the RAW scores; the exponent offset actually used is
-    // the integer M = -ceil(m * c), so every rescale factor exp2(M_new - M_old) is an exact power of two
-    // and l / acc are rescaled without rounding (p of the running max lies in (1/2, 1]).
-    float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
-    float acc[NV];
-#pragma unroll
-    for (int ch = 0; ch < NV; ++ch) acc[ch] = 0.f;
-
-    // online-softmax update with the 16 scores this lane holds of a 32-key sub-tile
-    auto update = [&](f32x16 s, int key0 /* first key of the sub-tile */, const float* vt, int ldsk0) {
-        const int kl = key0 + 4 * half;
-        if (CAUSAL || key0 + 32 > a.Lk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kl + (r & 3) + 8 * (r >> 2);
-                const bool ok = (key < a.Lk) && (!CAUSAL || key <= qi);
-                s[r] = ok ? s[r] : UM_NEG_MASK;
-            }
-        }
-        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
-        m = fmaxf(m, mx);
-        const float Mn = -ceilf(m * c);
-        const float resc = fast_exp2(Mn - M);
-        M = Mn;
-        l *= resc;
-#pragma unroll
-        for (int ch = 0; ch < NV; ++ch) acc[ch] *= resc;
-        const float mc = M;
-        float l0 = 0.f, l1 = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 vv[NV];
-#pragma unroll
-            for (int ch = 0; ch < NV; ++ch)
-                vv[ch] = *reinterpret_cast<const f32x4*>(vt + ch * TK + ldsk0 + 8 * g + 4 * half);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p = fast_exp2(__builtin_fmaf(s[4 * g + i], c, mc));
-                if (i & 1) l1 += p; else l0 += p;
-#pragma unroll
-                for (int ch = 0; ch < NV; ++ch) acc[ch] = __builtin_fmaf(p, vv[ch][i], acc[ch]);
-            }
-        }
-        l += l0 + l1;
-    };
-
-    // per-lane fragment address: row * 256 + ((2 ks + half) ^ (row & 15)) * 16  ==  kaddr ^ (ks << 5)
-    int kaddr;
-    {
-        const int r = lane & 31, x = r & 15;
-        kaddr = r * 256 + ((x >> 1) << 5) + ((half ^ (x & 1)) << 4);
-    }
-
-    // ---- prologue: tile 0 into slot 0 ----------------------------------------------------------------------
-    if (tbeg < tend) {
-#pragma unroll
-        for (int i = 0; i < NPIECE; ++i) k_piece(tbeg, i, lds);
-        v_piece(tbeg, lds);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    auto tile = [&](auto slot_c, int t) {
-        constexpr int SL = decltype(slot_c)::value;
-        const unsigned char* cur = lds + SL * SLOT;
-        unsigned char* nxt = lds + (SL ^ 1) * SLOT;
-        const bool staging = t + 1 < tend;
-        f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
-        {
-            i16x8 f0h[2], f0l[2], f1h[2], f1l[2];               // sub-tile 0 / 1 fragments, one k-step ahead
-            f0h[0] = *reinterpret_cast<const i16x8*>(cur + kaddr);
-            f1h[0] = *reinterpret_cast<const i16x8*>(cur + 32 * 256 + kaddr);
-            if (NS == 2) {
-                f0l[0] = *reinterpret_cast<const i16x8*>(cur + PLANE + kaddr);
-                f1l[0] = *reinterpret_cast<const i16x8*>(cur + PLANE + 32 * 256 + kaddr);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int bq = ks & 1, nb = bq ^ 1;
-                if (ks + 1 < 8) {
-                    const int ka = kaddr ^ ((ks + 1) << 5);
-                    f0h[nb] = *reinterpret_cast<const i16x8*>(cur + ka);
-                    f1h[nb] = *reinterpret_cast<const i16x8*>(cur + 32 * 256 + ka);
-                    if (NS == 2) {
-                        f0l[nb] = *reinterpret_cast<const i16x8*>(cur + PLANE + ka);
-                        f1l[nb] = *reinterpret_cast<const i16x8*>(cur + PLANE + 32 * 256 + ka);
-                    }
-                }
-                if (staging && (ks * NPIECE) % 8 == 0) k_piece(t + 1, ks * NPIECE / 8, nxt);
-                if (staging && ks == 7) v_piece(t + 1, nxt);
-                if (NS == 2) {
-                    s0 = T::mfma(f0l[bq], qf[0][ks], s0);
-                    s1 = T::mfma(f1l[bq], qf[0][ks], s1);
-                    s0 = T::mfma(f0h[bq], qf[NS - 1][ks], s0);
-                    s1 = T::mfma(f1h[bq], qf[NS - 1][ks], s1);
-                }
-                s0 = T::mfma(f0h[bq], qf[0][ks], s0);
-                s1 = T::mfma(f1h[bq], qf[0][ks], s1);
-            }
-            // fragment reads stay one k-step ahead of the MFMAs that consume them
-            constexpr int RD = 2 * NS, MF = 2 * ((NS == 2) ? 3 : 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-        }
-        const float* vt = reinterpret_cast<const float*>(cur + VOFF);
-        update(s0, t * TK, vt, 0);
-        update(s1, t * TK + 32, vt, 32);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t+1 has landed
-        __syncthreads();                                        // ... everyone's has; tile t is fully consumed
-    };
-    for (int t = tbeg; t < tend; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < tend) tile(std::integral_constant<int, 1>{}, t + 1);
-    }
-
-    // ---- merge the two half-waves' partial softmaxes and write ------------------------------------
-    const float M2 = __shfl_xor(M, 32);
-    const float l2 = __shfl_xor(l, 32);
-    const float MM = fminf(M, M2);
-    const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
-    const float lt = l * f1 + l2 * f2;
-    if (a.nsplit > 1) {          // partial result of this key range; gsv_combine_kernel finishes the softmax
-        float* pr = a.partial + (((long)blockIdx.z * gridDim.y + b) * a.Lq + qi) * (2 + NV);
-        if (half == 0 && qi < a.Lq) {
-            pr[0] = MM;
-            pr[1] = lt;
-        }
-#pragma unroll
-        for (int ch = 0; ch < NV; ++ch) {
-            const float a2 = __shfl_xor(acc[ch], 32);
-            if (half == 0 && qi < a.Lq) pr[2 + ch] = acc[ch] * f1 + a2 * f2;
-        }
-        return;
-    }
-#pragma unroll
-    for (int ch = 0; ch < NV; ++ch) {
-        const float a2 = __shfl_xor(acc[ch], 32);
-        const float at = acc[ch] * f1 + a2 * f2;
-        if (half == 0 && qi < a.Lq) {
-            float r = a.alpha * (at / lt);
-            if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi];
-            a.out[((long)b * NV + ch) * a.Lq + qi] = r;
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------------
-// gsv3_kernel: the same computation, software-pipelined at instruction level.
+// gsv3_kernel: software-pipelined at instruction level.
 //
-// What round 1's profile said about gsv_kernel (profiles/r01_pmc_final.json): 6.7 VALU instructions per MFMA, every wave
+// What round 1's profile said about its phase-structured predecessor (profiles/r01_pmc_final.json): 6.7 VALU instructions per MFMA, every wave
 // 49 % of its cycles stalled at issue and the matrix pipe busy 49 % -- a wave issued its 48 MFMAs of a tile back to back
 // (32 cycles each with nothing else issued), then ~320 VALU instructions of softmax with the matrix pipe idle unless the
 // co-resident wave happened to be in its MFMA phase.  Here
@@ -1150,31 +936,21 @@ static int gsv_choose_split(int qtiles, int nbatch, int ktiles) {
     return best;
 }
 
-// Kernel generation: default gsv4_kernel (one wave per SIMD, 64 queries per wave) wherever the key count is whole 64-key tiles
-// and the launch is not causal, else gsv3_kernel (software-pipelined, two waves per SIMD).  UM_GSV_V3=1 forces gsv3, UM_GSV_V2=1
-// round 1's phase-structured gsv_kernel (same-box A/B runs).  gsv3 / gsv4 operand planes carry sqrt(log2(e) / sqrt(C)) on both sides.
+// Kernel choice: gsv4_kernel (one wave per SIMD, 64 queries per wave) wherever the key count is whole 64-key tiles, the launch
+// is not causal and fills the chip, else gsv3_kernel (two waves per SIMD) -- a pure function of the call's arguments.
+// (Diagnostic builds only: UM_GSV_V3=1 forces gsv3 for same-box A/B runs.)  Operand planes carry sqrt(log2(e) / sqrt(C)) on both sides.
 static int gsv_version() {
     static const int v = [] {
-        const char* e2 = getenv("UM_GSV_V2");
-        const char* e3 = getenv("UM_GSV_V3");
-        return (e2 && *e2 == '1') ? 2 : ((e3 && *e3 == '1') ? 3 : 4);
+        const char* e3 = um_debug_env("UM_GSV_V3");
+        return (e3 && *e3 == '1') ? 3 : 4;
     }();
     return v;
 }
-static bool gsv_use_v2() { return gsv_version() == 2; }
-static float gsv_plane_scale(float scale_log2) { return gsv_use_v2() ? 1.f : sqrtf(scale_log2); }
+static float gsv_plane_scale(float scale_log2) { return sqrtf(scale_log2); }
 
 // gsv4: one workgroup per CU, all of them resident at once ("stream-K"): the (batch, 256-query tile, 64-key tile) units are cut
 // into equal chunks.  A chunk is at least 8 key tiles and a query tile is cut into at most GSV_MAX_SPLIT segments.
-static int gsv_num_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return cus;
-    }();
-    return n;
-}
+static int gsv_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 template <int NV, bool CAUSAL>
 static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hipStream_t stream) {
@@ -1191,7 +967,7 @@ static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hi
         const long min_chunk = (KT + GSV_MAX_SPLIT - 3) / (GSV_MAX_SPLIT - 2);     // at most GSV_MAX_SPLIT segments per query tile
         if (chunk < min_chunk) chunk = min_chunk;
         if (chunk < 8) chunk = 8;
-        static const bool whole = [] { const char* e = getenv("UM_GSV4_WHOLE_TILES"); return e && *e == '1'; }();   // A/B timing
+        static const bool whole = [] { const char* e = um_debug_env("UM_GSV4_WHOLE_TILES"); return e && *e == '1'; }();   // A/B timing
         if (!partial || (whole && chunk > KT)) chunk = ((chunk + KT - 1) / KT) * KT;   // no partial buffer: whole query tiles per workgroup
         a.chunk = (int)chunk;
         const bool direct = (chunk % KT) == 0;
@@ -1200,6 +976,7 @@ static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hi
         const unsigned wgs = (unsigned)((units + chunk - 1) / chunk);
         {
             ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
+            um_census_hit(UM_V_GSV4);
             if (mode == 0)
                 hipLaunchKernelGGL((gsv4_kernel<Fp16, 2, NV>), dim3(wgs), dim3(256), 0, stream, a);
             else
@@ -1219,12 +996,8 @@ static hipError_t launch_gsv(GsvArgs a, int nbatch, int mode, float* partial, hi
     dim3 grid(qtiles, nbatch, a.nsplit), block(256);
     {
         ScopedKernelTimer timer(UM_K_GLOBAL_SOFTMAX, stream);
-        if (ver == 2) {
-            if (mode == 0)
-                hipLaunchKernelGGL((gsv_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
-            else
-                hipLaunchKernelGGL((gsv_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
-        } else if (mode == 0) {
+        um_census_hit(UM_V_GSV3);
+        if (mode == 0) {
             hipLaunchKernelGGL((gsv3_kernel<Fp16, 2, NV, CAUSAL>), grid, block, 0, stream, a);
         } else {
             hipLaunchKernelGGL((gsv3_kernel<Bf16, 1, NV, CAUSAL>), grid, block, 0, stream, a);
@@ -1389,7 +1162,7 @@ extern "C" int um_prop_global_attn(const float* q, const float* k, const float* 
 }
 
 // The factor the operand planes of this file's kernels carry on BOTH sides (q and k): sqrt(log2(e) / sqrt(C)), so that the MFMA
-// result is the softmax logit in log2 units.  (1 when UM_GSV_V2=1 selects the round-1 kernel, which scales the scores instead.)
+// result is the softmax logit in log2 units.
 extern "C" float um_global_corr_plane_scale(int channels) {
     return channels > 0 ? gsv_plane_scale(UM_LOG2E / sqrtf((float)channels)) : 0.f;
 }

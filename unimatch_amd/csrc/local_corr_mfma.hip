@@ -372,6 +372,7 @@ extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, co
     if (blocks > 4096) blocks = 4096;
     {
         ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
+        um_census_hit(UM_V_K4_MFMA);
         hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
     }
     return (int)hipGetLastError();
@@ -419,6 +420,7 @@ extern "C" int um_local_corr_softmax_mfma(const float* f0, const float* f1, floa
     if (blocks > 4096) blocks = 4096;
     {
         ScopedKernelTimer timer(UM_K_LOCAL_CORR, stream);
+        um_census_hit(UM_V_K3_MFMA);
         hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
     }
     return (int)hipGetLastError();

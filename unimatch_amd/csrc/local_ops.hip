@@ -515,6 +515,7 @@ extern "C" int um_local_corr_softmax(const float* f0, const float* f1, float* ou
         return -4;
     }
     ScopedKernelTimer timer(UM_K_LOCAL_CORR, (hipStream_t)stream);
+    um_census_hit(UM_V_K3_VALU);
     hipLaunchKernelGGL(local_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
                        (hipStream_t)stream, f0, f1, out, batch, h, w, radius, one_d);
     return (int)hipGetLastError();
@@ -533,6 +534,7 @@ extern "C" int um_local_corr_with_flow(const float* f0, const float* f1, const f
     }
     const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
     ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
+    um_census_hit(UM_V_K4_VALU);
     hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0,
                        (hipStream_t)stream, f0, f1, flow, cost, batch, h, w, radius, (unsigned short*)nullptr, 0L, 0);
     return (int)hipGetLastError();
@@ -548,6 +550,7 @@ extern "C" int um_local_corr_with_flow_planes(const float* f0, const float* f1, 
     }
     const long nblocks = ((long)batch * h * w + K4_PIX - 1) / K4_PIX;
     ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
+    um_census_hit(UM_V_K4_VALU);
     hipLaunchKernelGGL(local_corr_with_flow_kernel, dim3(pixel_grid_blocks(nblocks)), dim3(256), 0, (hipStream_t)stream, f0, f1,
                        flow, (float*)nullptr, batch, h, w, radius, (unsigned short*)planes_out, plane_rows * ld, ld);
     return (int)hipGetLastError();

@@ -105,8 +105,23 @@ extern "C" int um_comm_init_rank(void** comm_out, const void* id, int rank, int 
     return 0;
 }
 
-// File bootstrap: rank 0 writes the id to `<path>.tmp` and renames it to `path` (atomic on one filesystem); the other ranks
-// poll for `path`.  The file is keyed by the caller (e.g. job id + port): a stale file from an earlier job must not be reused.
+// File bootstrap: rank 0 removes whatever is at `path`, writes {magic, world, wall-clock stamp, id} to `<path>.tmp` and renames it
+// to `path` (atomic on one filesystem); the other ranks poll for a record with the right magic and world that is younger than
+// UM_ID_FILE_MAX_AGE seconds (a file left behind by a crashed job of another day is ignored instead of handing out a dead id),
+// and rank 0 deletes the file once ncclCommInitRank has returned, i.e. after every rank has joined.  Two jobs must not share a
+// path at the same time: key it by job (unimatch_amd.dist.launch_ranks uses the rendezvous port and the launcher's pid).
+#define UM_ID_FILE_MAX_AGE 600
+namespace {
+struct IdRecord {
+    char magic[8];
+    int world;
+    int pad;
+    long long stamp;
+    unsigned char id[UM_COMM_ID_BYTES];
+};
+const char kIdMagic[8] = {'U', 'M', 'R', 'C', 'C', 'L', '0', '2'};
+}  // namespace
+
 extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, int world, int timeout_seconds) {
     if (!comm_out || !path || !*path || world <= 0 || rank < 0 || rank >= world) {
         um_set_error("um_comm_init_file: null pointer / empty path or rank %d outside [0, %d)", rank, world);
@@ -116,13 +131,18 @@ extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, in
         um_set_error("um_comm_init_file: path longer than 1000 bytes");
         return UM_ERR_BAD_ARG;
     }
-    unsigned char id[UM_COMM_ID_BYTES];
+    IdRecord rec;
     if (rank == 0) {
-        if (int e = um_comm_unique_id(id)) return e;
+        memset(&rec, 0, sizeof(rec));
+        memcpy(rec.magic, kIdMagic, sizeof(kIdMagic));
+        rec.world = world;
+        rec.stamp = (long long)time(nullptr);
+        if (int e = um_comm_unique_id(rec.id)) return e;
+        (void)unlink(path);                                         // a leftover of an earlier job under the same key
         char tmp[1024 + 8];
         snprintf(tmp, sizeof(tmp), "%s.tmp", path);
         FILE* f = fopen(tmp, "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id) || fclose(f) != 0 || rename(tmp, path) != 0) {
+        if (!f || fwrite(&rec, 1, sizeof(rec), f) != sizeof(rec) || fclose(f) != 0 || rename(tmp, path) != 0) {
             um_set_error("um_comm_init_file: cannot publish the unique id at %s", path);
             return UM_ERR_COLLECTIVE;
         }
@@ -131,18 +151,22 @@ extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, in
         for (;;) {
             FILE* f = fopen(path, "rb");
             if (f) {
-                const size_t n = fread(id, 1, sizeof(id), f);
+                const size_t n = fread(&rec, 1, sizeof(rec), f);
                 fclose(f);
-                if (n == sizeof(id)) break;
+                if (n == sizeof(rec) && memcmp(rec.magic, kIdMagic, sizeof(kIdMagic)) == 0 && rec.world == world &&
+                    (long long)time(nullptr) - rec.stamp <= UM_ID_FILE_MAX_AGE)
+                    break;
             }
             if (timeout_seconds >= 0 && time(nullptr) - t0 > timeout_seconds) {
-                um_set_error("um_comm_init_file: rank %d waited %d s for %s", rank, timeout_seconds, path);
+                um_set_error("um_comm_init_file: rank %d waited %d s for a fresh id record at %s", rank, timeout_seconds, path);
                 return UM_ERR_COLLECTIVE;
             }
             usleep(20000);
         }
     }
-    return um_comm_init_rank(comm_out, id, rank, world);
+    const int e = um_comm_init_rank(comm_out, rec.id, rank, world);
+    if (rank == 0) (void)unlink(path);                              // every rank has joined (or the bootstrap failed): single use
+    return e;
 }
 
 extern "C" int um_comm_world(void* comm) {

@@ -13,3 +13,5 @@ struct ScopedKernelTimer {
     ScopedKernelTimer(int kid, hipStream_t stream) : tok(um_timing_on() ? um_timing_begin(kid, stream) : nullptr), s(stream) {}
     ~ScopedKernelTimer() { um_timing_end(tok, s); }
 };
+
+void um_census_hit(int variant);   // UM_V_*: counts the launch when um_census_enable(1) is in effect

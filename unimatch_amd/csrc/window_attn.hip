@@ -26,6 +26,7 @@
 #include <type_traits>
 #include "common.h"
 #include "planes.h"
+#include "timing.h"
 
 // -DUM_TRACE: wave 0 / lane 0 of every 37th workgroup stamps s_memtime at section boundaries of its first 24 tiles
 // into the buffer given to um_debug_set_trace() (diagnostics only; tools/trace_attn.py).
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
         const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024"
-                     : : "v"(s0), "v"(s1), "s"(dst) : "memory");
+                     : : "v"(s0), "v"(s1), "s"(dst) : "memory", "m0");
     };
 
     const int li = lane & 15, lg = (lane >> 4) & 1;
@@ -778,18 +779,10 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               const unsigned short* wq = nullptr, void* ks_ws = nullptr, size_t ks_ws_bytes = 0);
 
 // ---- key split for small launches (see KSPLIT in the kernel): only while every workgroup of the launch is resident at once
-static int wattn_num_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return n;
-}
+static int wattn_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 static int wattn_key_split(int total, int ntiles) {
-    static const bool off = getenv("UM_WATTN_NO_KSPLIT") != nullptr;      // A/B switch
+    static const bool off = um_debug_env("UM_WATTN_NO_KSPLIT") != nullptr;      // A/B switch
     if (off) return 1;
     const int cus = wattn_num_cus();
     int split = 1;
@@ -969,7 +962,7 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.total = a.nqt * a.nwin * streams;
     a.scale_log2 = UM_LOG2E / sqrtf((float)UM_CHANNELS);
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
-    static const float headroom = [] { const char* e = getenv("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
+    static const float headroom = [] { const char* e = um_debug_env("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
     if (wm && wq && ks_ws) {
         const int split = wattn_key_split(a.total, (a.n + 31) / 32);
@@ -980,6 +973,7 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
         }
     }
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
+    um_census_hit(a.split > 1 ? UM_V_WATTN_KSPLIT : UM_V_WATTN_TILE);
     if (wm && wq && a.split > 1) {
         if (mode == 0)
             hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(a.total * a.split), dim3(256), 0, stream, a);

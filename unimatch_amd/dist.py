@@ -52,12 +52,21 @@ class RcclGather:
             if id_file:
                 code = self.lib.um_comm_init_file(ctypes.byref(self.comm), os.fsencode(id_file), rank, world, timeout)
             else:
+                # Rank 0 ALWAYS broadcasts -- the id, or the reason it could not get one -- so that every rank passes through
+                # the same collective and then raises the same error (a rank-0-only exception in front of the broadcast left
+                # the other ranks blocked in it).
                 uid = (ctypes.c_ubyte * _abi.COMM_ID_BYTES)()
+                box = [None]
                 if rank == 0:
-                    _abi.check(self.lib.um_comm_unique_id(uid), 'um_comm_unique_id')
-                box = [bytes(uid)]
+                    try:
+                        _abi.check(self.lib.um_comm_unique_id(uid), 'um_comm_unique_id')
+                        box = [bytes(uid)]
+                    except Exception as exc:                        # noqa: BLE001 -- travels to every rank
+                        box = [('error', f'{type(exc).__name__}: {exc}')]
                 if world > 1:
                     dist.broadcast_object_list(box, src=0)
+                if not isinstance(box[0], bytes):
+                    raise RuntimeError(f'RcclGather: rank 0 could not create the RCCL unique id ({box[0][1] if box[0] else "?"})')
                 uid = (ctypes.c_ubyte * _abi.COMM_ID_BYTES).from_buffer_copy(box[0])
                 code = self.lib.um_comm_init_rank(ctypes.byref(self.comm), uid, rank, world)
         _abi.check(code, 'um_comm_init')
@@ -105,16 +114,39 @@ class TorchGather:
         pass
 
 
+def make_gather(rank, world, device, id_file=None):
+    """The data-path collective of a multi-rank job: ``(gather, description)``.  Tries the library's own communicator
+    (``RcclGather``); every rank then agrees -- one MIN all-reduce on the launcher's group -- on whether ALL of them
+    succeeded, and if not all fall back together to ``TorchGather`` (never a mix: mismatched collectives hang)."""
+    kind = 'um_allgather_preds (ncclAllGather through the C ABI, own communicator)'
+    gather, ok = None, 1
+    try:
+        gather = RcclGather(rank, world, device, id_file=id_file)
+    except Exception as exc:                                        # noqa: BLE001 -- reported in the description
+        kind, ok = f'torch.distributed all_gather_into_tensor (um_comm_init failed: {exc})'[:240], 0
+    if world > 1 and dist.is_initialized():
+        flag = torch.tensor([ok], device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and ok:
+            gather.close()
+            gather, ok = None, 0
+            kind = 'torch.distributed all_gather_into_tensor (um_comm_init failed on another rank)'
+    if gather is None:
+        gather = TorchGather(rank, world, device)
+    return gather, kind
+
+
 _GATHER = None
 
 
 def rccl_gather(device=None):
-    """The process-wide RcclGather of an initialised multi-rank job on GPUs (created on first use)."""
+    """The process-wide prediction gather of an initialised multi-rank job on GPUs (created on first use; the library's RCCL
+    communicator, or -- agreed by all ranks -- ``torch.distributed`` when that cannot be built)."""
     global _GATHER
     if _GATHER is None:
         rank, world = dist.get_rank(), dist.get_world_size()
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        _GATHER = RcclGather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
+        _GATHER, _ = make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
     return _GATHER
 
 
@@ -138,6 +170,14 @@ def launch_ranks(script, script_args, nproc, need_gpus=True, env=None):
     e = dict(os.environ if env is None else env)
     e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')                 # dmabuf IPC only on these hosts (RCCL needs it)
     return subprocess.call(cmd, env=e)
+
+
+def job_id_file(port=None):
+    """A job-unique path for ``um_comm_init_file`` (rendezvous port + launcher pid), for callers that bootstrap the
+    communicator without ``torch.distributed``."""
+    import tempfile
+    port = port if port is not None else os.environ.get('MASTER_PORT', '0')
+    return os.path.join(tempfile.gettempdir(), f'um_rccl_id_{port}_{os.getppid()}')
 
 
 def shard_bounds(batch, rank, world):

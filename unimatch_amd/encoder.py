@@ -6,7 +6,6 @@ Architecture and parameter names follow /root/reference/unimatch/backbone.py:39-
 unimatch/trident_conv.py:10-90 so that reference checkpoints load unchanged
 (``backbone.conv1.weight``, ``backbone.layer2.0.downsample.0.bias``, ``backbone.trident_conv.weight`` ...).
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -129,6 +128,8 @@ class CNNEncoder(nn.Module):
         return self.trident_conv(x) if self.num_branch > 1 else [x]       # high -> low resolution
 
 
+    shortcut_f32 = False
+
     def _forward_nhwc(self, x, ops, input_norm=None):
         """The whole encoder in channels-last layout on the library's convolution / normalisation kernels
         (``um_stem_conv_fwd``, ``um_conv2d_fwd``, ``um_nhwc_instance_norm``).  The returned maps are NCHW *views* of NHWC memory, so
@@ -136,7 +137,7 @@ class CNNEncoder(nn.Module):
         b = x.shape[0]
         y, h, w = ops.stem_conv(x.contiguous(), self.conv1.weight, input_norm, stats=True)    # fp32 NHWC [b*h*w, 64]
         c = y.shape[1]
-        keep_f32 = os.environ.get('UM_SHORTCUT_F32') == '1'      # A/B switch (tools/ab_bench.py): fp32 copies for the shortcuts
+        keep_f32 = self.shortcut_f32                            # A/B knob (tools/ab_bench.py --set): fp32 copies for the shortcuts
         planes, f32 = ops.nhwc_norm(y, b, h * w, relu=True, want_planes=True, want_f32=keep_f32, conv_stats=ops.last_conv_stats)
         act = (planes, f32, b, h, w, c)
         blocks = [blk for layer in (self.layer1, self.layer2, self.layer3) for blk in layer]

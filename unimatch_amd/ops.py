@@ -6,7 +6,6 @@ the HIP kernels on torch's current stream through ``ctypes``.  Feature tensors a
 ``[N, L, C]`` fp32 (C = 128); flow-like tensors are ``[N, V, h, w]`` fp32 as in the reference.
 """
 import ctypes
-import os
 import weakref
 
 import torch
@@ -60,9 +59,9 @@ class HipOps:
 
     fused_tail = True          # Transformer-layer linears / LayerNorm / GELU / residual run on um_linear_fwd
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
-    fused_merge = os.environ.get('UM_NO_MERGE') != '1'   # merge + LayerNorm (+ residual) in the attention kernel's epilogue
-    fused_qproj = os.environ.get('UM_QPROJ', '1') == '1'   # ... and the query projection in its prologue
-                                                         # (um_window_attn_merge_fwd); the env switch is for A/B timing
+    fused_merge = True         # merge + LayerNorm (+ residual) in the attention kernel's epilogue
+    fused_qproj = True         # ... and the query projection in its prologue (um_window_attn_qproj_merge_fwd)
+    # (class attributes: tests and tools/ab_bench.py flip them programmatically; the product reads no environment variable)
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
     WSHIFT = 10                # weights are scaled by 2^10 before the fp16 split (exact), see linear.hip
@@ -269,14 +268,15 @@ class HipOps:
 
     def _split_workspace(self, name, nbytes, device):
         """Scratch of a split small launch (attention: key split, FFN: hidden split -- partial results + flags): zero at
-        allocation, left zero by every launch; one buffer per kernel and device, grown on demand (launches of this object
-        run on one stream at a time)."""
+        allocation, left zero by every launch; one buffer per kernel, device AND stream (two launches in flight on different
+        streams must not share the flags), grown on demand."""
         if not nbytes:
             return None
         cache = self.__dict__.setdefault(name, {})
-        buf = cache.get(device)
+        key = (device, _stream())
+        buf = cache.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = cache[device] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            buf = cache[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         return buf
 
     def window_attention_qproj_merge(self, x, q_weight, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate,
@@ -506,61 +506,25 @@ class HipOps:
         _check_tokens('f0', f0, tokens=h * w)
         _check_tokens('f1', f1, b, l)
         flow = flow.contiguous()
-        feat = self._k4_feat_planes(f0, f1, h, w, radius) if self._k4_want_mfma() else None
+        feat = self._k4_feat_planes(f0, f1, h, w, radius)
         if feat is not None:
-            stats = self._k4_stats_begin(f0.device)
             code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
                 _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), None, _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius,
-                self.k4_flags, _ptr(stats), _stream()))
+                self.k4_flags, None, _stream()))
             _abi.check(code, 'um_local_corr_with_flow_feat')
-            self._k4_stats_end()
             return
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_planes(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(dest), ld, dest.numel() // (4 * ld), b, h, w, c, radius, _stream()))
         _abi.check(code, 'um_local_corr_with_flow_planes')
 
-    k4_mfma = os.environ.get('UM_K4_MFMA', '1') != '0'     # cost volume on the matrix cores where the flow is coherent
-    k4_flags = 1 if os.environ.get('UM_K4_FORCE_VALU') == '1' else 0
-
-    # Adaptive dispatch of the cost volume.  The matrix-core kernel is 3.6 - 7.6x faster where the flow is locally coherent (any
-    # trained model) and ~3 % slower than the VALU kernel where it is not (random-init weights; it also spends a feature split
-    # per scale).  The kernel counts the tiles that took each path; the counters come back with a non-blocking copy and are
-    # read -- never waited for -- before a later call.  Mostly incoherent: the VALU kernel serves the following calls, and
-    # every K4_PROBE-th call measures again.  UM_K4_ADAPTIVE=0 pins the matrix-core kernel.
-    K4_PROBE = 32
-    k4_adaptive = os.environ.get('UM_K4_ADAPTIVE', '1') != '0'
-
-    def _k4_want_mfma(self):
-        if not self.k4_mfma:
-            return False
-        st = self.__dict__.setdefault('_k4_state', {'use': True, 'since_probe': 0, 'event': None, 'dev': None, 'host': None})
-        if st['event'] is not None and st['event'].query():
-            coh, inc = int(st['host'][0]), int(st['host'][1])
-            st['event'] = None
-            if self.k4_adaptive and coh + inc > 0:
-                st['use'] = inc * 2 < coh + inc
-        if st['use'] or not self.k4_adaptive:
-            return True
-        st['since_probe'] += 1
-        if st['since_probe'] >= self.K4_PROBE:
-            st['since_probe'] = 0
-            return True
-        return False
-
-    def _k4_stats_begin(self, device):
-        st = self._k4_state
-        if st['dev'] is None or st['dev'].device != device:
-            st['dev'] = torch.zeros(2, dtype=torch.int32, device=device)
-            st['host'] = torch.zeros(2, dtype=torch.int32).pin_memory()
-        return st['dev']
-
-    def _k4_stats_end(self):
-        st = self._k4_state
-        if st['event'] is None:                       # one read-back in flight at a time
-            st['host'].copy_(st['dev'], non_blocking=True)
-            st['dev'].zero_()
-            st['event'] = torch.cuda.Event()
-            st['event'].record()
+    # Cost-volume dispatch is a PURE FUNCTION of the call's arguments: radius 4 on a map of whole 8 x 4 pixel tiles goes to the
+    # matrix-core kernel (k4m_kernel), whose own per-tile test -- does the tile's flow fit one 32 x 24 window? -- picks the
+    # product path or the gather path from the flow values alone; every other geometry goes to the VALU kernel.  Two forwards
+    # on the same inputs therefore run the same instructions (bitwise-equal outputs, HIP-graph capture freezes nothing).
+    # Round 2 routed launches by a tile-coherence counter read back asynchronously; that made the choice timing dependent
+    # for ~3 % on incoherent flow (k4m's gather path 0.661 ms against 0.643 ms at 4 x 128 x 192) and is gone.
+    k4_mfma = True             # False: VALU kernels everywhere (tests compare the two; tools A/B them)
+    k4_flags = 0               # bit 0: force k4m_kernel's per-pixel path for every tile (diagnostics)
 
     def _k4_feat_planes(self, f0, f1, h, w, radius):
         """fp16 hi | lo operand planes of (f0, f1) for um_local_corr_with_flow_feat, or None where that kernel does not apply.
@@ -774,14 +738,12 @@ class HipOps:
         k = 2 * radius + 1
         out = torch.empty((b, k * k, h, w), dtype=torch.float32, device=f0.device)
         meta = {'flops': 2.0 * b * l * (k + 1) ** 2 * c, 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l + 4.0 * k * k * b * l}
-        feat = self._k4_feat_planes(f0, f1, h, w, radius) if self._k4_want_mfma() else None
+        feat = self._k4_feat_planes(f0, f1, h, w, radius)
         if feat is not None:
-            stats = self._k4_stats_begin(f0.device)
             code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
                 _ptr(f0), _ptr(f1), _ptr(feat), _ptr(flow), _ptr(out), None, 0, 0, b, h, w, c, radius, self.k4_flags,
-                _ptr(stats), _stream()), meta)
+                None, _stream()), meta)
             _abi.check(code, 'um_local_corr_with_flow_feat')
-            self._k4_stats_end()
             return out
         code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow(
             _ptr(f0), _ptr(f1), _ptr(flow), _ptr(out), b, h, w, c, radius, _stream()), meta)
