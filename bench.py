@@ -95,6 +95,21 @@ def pmc_traffic(kernel_key, files):
         return None, 'no PMC pass on record for this launch shape'
 
 
+def pmc_mfma_busy(kernel_key, files):
+    """Matrix-pipe busy fraction of the kernel from the tracked PMC pass: SQ_VALU_MFMA_BUSY_CYCLES (= 32 cycles per 32x32x16
+    MFMA, summed over all SIMDs) / (1024 SIMDs x kernel cycles, kernel cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8).
+    Source-stamped like the traffic figure: None when the kernel source changed since the pass."""
+    try:
+        pm = json.load(open(PMC_FILE))
+        rec = pm[kernel_key]
+        if rec.get('source_stamp') != source_stamp(files) or 'mfma_busy' not in rec:
+            return None, 'stale or absent: no SQ pass on record for this kernel source'
+        return rec['mfma_busy'], (f"SQ_VALU_MFMA_BUSY_CYCLES {rec['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} / (1024 SIMDs x GRBM_GUI_ACTIVE "
+                                  f"{rec['GRBM_GUI_ACTIVE']:.0f} / 8 XCDs), rocprofv3 --pmc pass at {pm.get('git', '?')}")
+    except (OSError, KeyError, ValueError):
+        return None, 'no PMC pass on record for this launch shape'
+
+
 def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch, flops_attn_fused=0.0):
     """`achieved` / `frac` price the SURVEY 8(d) figure of the kernel's function alone (attention: 4 L n C per stream); the
     merge Linear and query projection the attention launch also executes are reported beside it, never inside it."""
@@ -113,11 +128,13 @@ def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch, flops_attn_fus
         dur = ms / n * 1e-3
         ach = fl / dur
         traffic, note = pmc_traffic(key, files) if batch == BATCH else (None, 'non-default batch')
+        busy, busy_note = pmc_mfma_busy(key, files) if batch == BATCH else (None, 'non-default batch')
         out.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic,
                     'traffic_unit': 'MB per launch', 'traffic_source': note, 'launches': n,
                     'avg_launch_ms': round(ms / n, 4), 'algorithmic_gflop_per_launch': round(fl / 1e9, 2),
                     'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
+                    'mfma_busy': busy, 'mfma_busy_source': busy_note,
                     'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
                     'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4)})
         if name == 'window_attn_kernel' and flops_attn_fused:
@@ -200,6 +217,8 @@ def main():
             pending['i'] += 1
         return pred
 
+    step_ms = []
+
     def timed(precision, steps, warmup):
         model.set_precision(precision)
         for _ in range(warmup):
@@ -212,15 +231,22 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+        # per-step device time for the MEDIAN: one event between steps on the compute stream, read after the timed
+        # region (no host synchronisation inside it); `value` stays K steps / wall time of the bracketed region (the contract)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for k in range(steps):
             pred = step()
+            marks[k + 1].record()
         finish_gather()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        step_ms.clear()
+        step_ms.extend(sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps)))
         lib.um_timing_enable(0)
         if distributed:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -229,6 +255,8 @@ def main():
         return elapsed, pred, collect(lib, 0), collect(lib, 1), collect(lib, 2)
 
     elapsed, pred, attn_t, gsv_t, split_t = timed(args.precision, args.steps, args.warmup)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    spread_ms = (step_ms[0], step_ms[-1])
     other = 'fast' if args.precision == 'exact' else 'exact'
     extra = None
     if not args.no_fast:
@@ -291,8 +319,10 @@ def main():
         epe = {'gpu_vs_fp64_truth': round(_epe(g, truth), 6), 'cpu_fp32_vs_fp64_truth': round(_epe(ref, truth), 6),
                'gpu_vs_cpu_fp32': round(_epe(g, ref), 6), 'precision': args.precision,
                'note': 'mean end-point error in pixels at full resolution on 1 sample pair; the middle figure is '
-                       'the fp32 reference-port noise floor at random-init weights (profiles/r02_parity_fullsize.txt has '
-                       'all five configs, thread-order noise and a conditioned-weights run with the absolute 1e-3 gate)'}
+                       'the fp32 reference-port noise floor at random-init weights.  Every sample of the batch, both image '
+                       'kinds, 3 seeds, all five configs at their own batch: profiles/r03_parity_batch.txt (weights: the '
+                       'reference constructor under seed 326, and the BUILDER-DEFINED conditioned set synth.CONDITIONED for '
+                       'the absolute 1e-3 px gate)'}
         if extra is not None:
             epe_other = round(_epe(extra[1][:1].cpu(), truth), 6)
         # the same port on this GPU with stock PyTorch-ROCm eager ops (factories default to the device inside the context)
@@ -331,6 +361,8 @@ def main():
     line = {
         'metric': 'image_pairs_per_sec', 'value': round(value, 3), 'unit': 'pairs/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'ms_per_step_median': round(median_ms, 3), 'ms_per_step_min_max': [round(spread_ms[0], 3), round(spread_ms[1], 3)],
+        'pairs_per_sec_at_median': round(b / (median_ms * 1e-3), 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f16x2' if args.precision == 'exact' else 'bf16',
         'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,

@@ -518,43 +518,6 @@ def test_end_to_end_exact_mode(name, golden):
         assert (pred - g[f'{name}.fp32']).abs().mean().item() < 1e-3
 
 
-def _parity_tool():
-    import importlib.util
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'parity_fullsize.py')
-    spec = importlib.util.spec_from_file_location('parity_fullsize', path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
-@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
-def test_full_size_parity_absolute_gate(cfg):
-    """The north star's gate -- EPE delta < 1e-3 px against the reference forward on identical inputs -- at the FULL size of
-    every BASELINE.json config (one pair), with the conditioned weight set (``synth.CONDITIONED``: soft softmaxes; the fp32
-    reference port itself agrees with an fp64 evaluation to ~1e-5 px there, so an absolute gate is meaningful).  The GPU
-    output must also stay within 3x of the fp32 port's own distance to fp64.  (tools/parity_fullsize.py prints the whole
-    table incl. random-init weights and thread-order noise: profiles/r02_parity_fullsize.txt.)"""
-    pf = _parity_tool()
-    rec = pf.cpu_legs(cfg, 'conditioned', min(32, __import__('os').cpu_count() or 8), 1, noise=False)
-    got = pf.gpu_leg(cfg, 'conditioned', 'exact')
-    e_gpu, e_port = pf.epe(got, rec['o64']), pf.epe(rec['o32'], rec['o64'])
-    assert e_gpu < 1e-3 and e_gpu <= 3.0 * e_port + 1e-5, (cfg, e_gpu, e_port)
-
-
-@pytest.mark.parametrize('cfg', [1, 2, 5])
-def test_full_size_parity_random_init_noise_floor(cfg):
-    """Random-init weights at full size: the one-scale configs sit on the fp32 noise floor (3e-3 .. 8e-3 px between the
-    fp32 port and fp64); the GPU must be within 1.5x of the port's own error.  The two-scale + refinement configs (3, 4)
-    are chaotic at random init -- the fp32 port is 26 / 71 px from fp64 and 25 / 69 px from ITSELF at another thread count
-    (profiles/r02_parity_fullsize.txt) -- so no comparison means anything there; they are gated with conditioned weights."""
-    pf = _parity_tool()
-    rec = pf.cpu_legs(cfg, 'random', min(32, __import__('os').cpu_count() or 8), 1, noise=False)
-    got = pf.gpu_leg(cfg, 'random', 'exact')
-    e_gpu, e_port = pf.epe(got, rec['o64']), pf.epe(rec['o32'], rec['o64'])
-    assert e_gpu <= 1.5 * e_port + 1e-4, (cfg, e_gpu, e_port)
-
-
 def test_end_to_end_bidirectional_and_batch(golden):
     pred, truth, _ = run_product('gmflow_s1', extra=dict(pred_bidir_flow=True))
     assert pred.shape == (2, 2, 64, 96)
@@ -1131,7 +1094,6 @@ def test_cost_volume_matrix_core_path(ops, kind):
     t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
     want = hp.local_corr_with_flow(f0.double(), f1.double(), flow.double(), 4)
     assert ops._k4_feat_planes(t0, t1, h, w, 4) is not None               # the matrix-core entry point serves this geometry
-    ops.k4_adaptive = False                                               # pin that kernel (no routing by measured coherence)
     got = ops.local_corr_with_flow(t0, t1, flow.to(DEV), h, w, 4)
     scale = max(1.0, want.abs().max().item())
     assert err(got, want)[1] < 3e-6 * scale, (kind, err(got, want))
@@ -1149,35 +1111,77 @@ def test_cost_volume_matrix_core_path(ops, kind):
     assert (back - got).abs().max().item() < 2e-6 * scale
     assert torch.equal(pl[:, :rows, 81:], torch.zeros(2, rows, 15, device=DEV))
     assert torch.equal(pl[:, rows], torch.zeros(2, 96, device=DEV))
-    ops.k4_adaptive = True
 
 
-def test_cost_volume_adaptive_dispatch():
-    """The matrix-core cost-volume kernel reports how many tiles took its pixel-at-a-time path; HipOps reads the counters
-    without ever waiting for them and routes the following launches to the VALU kernel while the flow is mostly incoherent,
-    probing again every K4_PROBE calls.  Either kernel gives the same cost volume (to rounding)."""
+def test_cost_volume_dispatch_is_a_pure_function_of_the_call():
+    """Which kernel serves the cost volume depends on the call's geometry only (radius 4 on whole 8 x 4 tiles: k4m_kernel, whose
+    per-tile product / gather choice depends on the flow values only) -- never on earlier calls or on timing (round 2 routed by
+    an asynchronously read counter).  Interleaving coherent and incoherent launches in any order gives bitwise-equal results
+    for equal inputs, and the launch census shows the same kernel every time."""
+    from unimatch_amd import _abi
     o = HipOps('exact')
-    o.K4_PROBE = 3
+    lib = _abi.load()
     b, h, w = 1, 32, 48
     f0, f1 = rnd(150, b, C, h, w), rnd(151, b, C, h, w)
     t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
     noisy = rnd(152, b, 2, h, w, scale=20.0).to(DEV)
     smooth = torch.full((b, 2, h, w), 1.3, device=DEV)
-    want_noisy = hp.local_corr_with_flow(f0.double(), f1.double(), noisy.cpu().double(), 4)
-    want_smooth = hp.local_corr_with_flow(f0.double(), f1.double(), smooth.cpu().double(), 4)
-    assert o._k4_want_mfma()                                            # starts on the matrix-core kernel
-    for _ in range(3):
-        got = o.local_corr_with_flow(t0, t1, noisy, h, w, 4)
-        torch.cuda.synchronize()
-        assert err(got, want_noisy)[1] < 3e-6 * max(1.0, want_noisy.abs().max().item())
-    assert o._k4_state['use'] is False                                   # measured: incoherent -> VALU kernel from here on
-    used = []
-    for _ in range(8):                                                   # coherent flow now: the next probe switches back
-        used.append(o._k4_state['use'])
-        got = o.local_corr_with_flow(t0, t1, smooth, h, w, 4)
-        torch.cuda.synchronize()
-        assert err(got, want_smooth)[1] < 3e-6 * max(1.0, want_smooth.abs().max().item())
-    assert o._k4_state['use'] is True and used[0] is False
+    want = {id(noisy): hp.local_corr_with_flow(f0.double(), f1.double(), noisy.cpu().double(), 4),
+            id(smooth): hp.local_corr_with_flow(f0.double(), f1.double(), smooth.cpu().double(), 4)}
+    lib.um_census_enable(1)
+    first = {}
+    for flow in (noisy, noisy, smooth, noisy, smooth, smooth, noisy, noisy, noisy, smooth):
+        got = o.local_corr_with_flow(t0, t1, flow, h, w, 4)
+        assert err(got, want[id(flow)])[1] < 3e-6 * max(1.0, want[id(flow)].abs().max().item())
+        if id(flow) in first:
+            assert torch.equal(got, first[id(flow)])
+        first[id(flow)] = got
+    census = _abi.census(lib)
+    lib.um_census_enable(0)
+    assert census['k4_mfma'] == 10 and census['k4_valu'] == 0
+    # a geometry the matrix-core kernel does not serve (width not a multiple of 8) always takes the VALU kernel
+    lib.um_census_enable(1)
+    f0b, f1b = rnd(153, 1, C, 12, 20), rnd(154, 1, C, 12, 20)
+    o.local_corr_with_flow(tok(f0b).to(DEV), tok(f1b).to(DEV), rnd(155, 1, 2, 12, 20, scale=3.0).to(DEV), 12, 20, 4)
+    assert _abi.census(lib)['k4_valu'] == 1 and _abi.census(lib)['k4_mfma'] == 0
+    lib.um_census_enable(0)
+
+
+def _refine_model(name, gain=0.02):
+    ck, fk = CONFIGS[name]
+    model = UniMatch(**ck).eval()
+    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=gain))
+    return model.to(DEV), fk
+
+
+@pytest.mark.parametrize('name', ['gmflow_s2_rr6', 'gmstereo_s2_rr3'])
+def test_refinement_configs_are_run_to_run_reproducible(name):
+    """Two forwards of a two-scale + refinement config on the same inputs are BITWISE equal, and so is a third one from a fresh
+    module (no state carried on HipOps between forwards decides anything): config 3 / 4 outputs are reproducible."""
+    model, fk = _refine_model(name, gain=1.0)                           # random init: incoherent scale-1 flow, the case that flipped
+    i0, i1 = synth_images(2, 128, 192, seed=77, kind='shift', normalized=(fk['task'] != 'flow'))
+    i0, i1 = i0.to(DEV), i1.to(DEV)
+    a = model(i0, i1, **fk)['flow_preds'][0]
+    b = model(i0, i1, **fk)['flow_preds'][0]
+    model2, _ = _refine_model(name, gain=1.0)
+    c = model2(i0, i1, **fk)['flow_preds'][0]
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_hip_graph_replay_matches_eager_with_refinement():
+    """HIP-graph capture of a refinement config (cost volume x 6 inside the GRU loop): replay is bitwise equal to eager, on the
+    captured inputs and on new ones (nothing about the cost-volume dispatch is frozen into the graph)."""
+    from unimatch_amd.graph import GraphedUniMatch
+    model, fk = _refine_model('gmflow_s2_rr6')
+    graphed = GraphedUniMatch(model)
+    for seed in (15, 16, 17):
+        i0, i1 = synth_images(1, 128, 192, seed=seed, kind='shift' if seed != 17 else 'noise')
+        i0, i1 = i0.to(DEV), i1.to(DEV)
+        want = model(i0, i1, **fk)['flow_preds'][0]
+        got = graphed(i0, i1, **fk)['flow_preds'][0]
+        assert torch.equal(got, want), seed
+    assert len(graphed._graphs) == 1 and all(v is not False for v in graphed._graphs.values())
 
 
 def test_local_corr_softmax_matrix_core_path(ops):
@@ -1197,3 +1201,96 @@ def test_local_corr_softmax_matrix_core_path(ops):
         finally:
             ops.k4_mfma = True
         assert err(got, want)[1] < 2e-5 and err(valu, want)[1] < 2e-5, (sc, err(got, want), err(valu, want))
+
+
+# ------------------------------------------------------------------ small-launch hand-offs under load; RCCL at world size 1
+def test_split_handoffs_repeat_under_uneven_load():
+    """The key-split attention and hidden-split FFN launches hand partial results from workgroup to workgroup through memory
+    (agent-scope accesses + a flag, workspace left zero by every launch).  A race there would be intermittent, so: > 200
+    launches per kernel at the batch-1 geometries, each compared BITWISE with the first (the merge order is fixed), while a
+    second stream keeps the memory system unevenly busy; the census proves the split instantiations ran and the workspaces
+    must be all-zero afterwards."""
+    from unimatch_amd import _abi
+    o = HipOps('exact')
+    lib = _abi.load()
+    c = 128
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)              # 256 MB: streaming traffic on the side stream
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    lib.um_census_enable(1)
+    launches = 0
+    for gi, (s_, h, w, wh, ww, sh, sw, rot) in enumerate([(1, 32, 48, 32, 48, 0, 0, 0), (2, 40, 56, 20, 28, 10, 14, 1),
+                                                          (1, 64, 96, 32, 48, 16, 24, 0), (2, 32, 48, 16, 24, 8, 12, 1)]):
+        m = s_ * h * w
+        x = rnd(700 + gi, m, c, scale=1.5).to(DEV)
+        xt = rnd(710 + gi, m, c, scale=1.5).to(DEV)
+        wq, wk, wv, wm = (rnd(720 + 4 * gi + i, c, c, scale=0.09).to(DEV) for i in range(4))
+        kv, _, n2 = o.linear_planes(xt, (wk, wv))
+        ref = None
+        for it in range(55):
+            if it % 3 != 2:                                                   # two launches under load, one on a quiet chip
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    big.mul_(1.0001) if it % 2 else big[: big.numel() // 2].copy_(big[big.numel() // 2:])
+            got = o.window_attention_qproj_merge(x, wq, (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, wh, ww, sh, sw, rot, wm, norm, x)
+            launches += 1
+            if ref is None:
+                ref = got
+                assert torch.isfinite(ref).all()
+            else:
+                assert torch.equal(got, ref), (gi, it)
+    census = _abi.census(lib)
+    assert census['wattn_ksplit'] == launches >= 200 and census['wattn_tile'] == 0, census
+    w1 = rnd(740, 1024, 256, scale=0.08).to(DEV)
+    w2 = rnd(741, 128, 1024, scale=0.06).to(DEV)
+    launches = 0
+    for gi, m in enumerate([2 * 2240, 2 * 6144, 2 * 4800, 1000]):
+        x, y = rnd(750 + gi, m, c, scale=1.5).to(DEV), rnd(760 + gi, m, c, scale=1.5).to(DEV)
+        ref = None
+        for it in range(55):
+            if it % 3 != 2:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    big.mul_(1.0001) if it % 2 else big[: big.numel() // 2].copy_(big[big.numel() // 2:])
+            got = o.ffn_ln(x, y, w1, w2, norm)
+            launches += 1
+            if ref is None:
+                ref = got
+                assert torch.isfinite(ref).all()
+            else:
+                assert torch.equal(got, ref), (gi, it)
+    census = _abi.census(lib)
+    lib.um_census_enable(0)
+    assert census['ffn_hsplit'] == launches >= 200 and census['ffn_tile'] == 0, census
+    torch.cuda.synchronize()
+    for name in ('_ks_ws', '_ffn_ws'):
+        for buf in getattr(o, name).values():
+            assert int(buf.count_nonzero()) == 0, name                       # every launch left its flags and slots' flags zero
+
+
+def test_rccl_allgather_at_world_size_one(tmp_path):
+    """The library's own collective path (um_comm_unique_id -> um_comm_init_rank -> um_allgather_preds = ncclAllGather, RCCL
+    bound by dlopen) at world size 1, where the all-gather degenerates to a copy: both bootstraps (id handed over directly /
+    through a file, which rank 0 must remove again once the communicator is up)."""
+    from unimatch_amd.dist import RcclGather, make_gather
+    dev = torch.device('cuda', torch.cuda.current_device())
+    x = rnd(800, 3, 2, 40, 56).to(DEV)
+    g = RcclGather(0, 1, dev)
+    assert g.ranks() == 1
+    out = g.all_gather(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out2 = g.all_gather(x, stream=side)                                       # the side stream bench.py gathers on
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 2, 40, 56) and torch.equal(out[0], x) and torch.equal(out2[0], x)
+    g.close()
+    path = tmp_path / 'um_rccl_id'
+    path.write_bytes(b'stale record of an earlier job' * 8)                   # must be replaced, not trusted
+    g = RcclGather(0, 1, dev, id_file=str(path))
+    out = g.all_gather(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], x) and not path.exists()
+    g.close()
+    gather, kind = make_gather(0, 1, dev)                                      # what bench.py / all_gather_predictions use
+    assert 'um_allgather_preds' in kind and gather.ranks() == 1
+    gather.close()

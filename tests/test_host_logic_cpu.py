@@ -5,6 +5,7 @@ import ctypes
 import inspect
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -97,6 +98,28 @@ def test_state_dict_names_and_param_counts():
         assert key in sd, key
     assert 'upsampler.0.weight' in UniMatch().state_dict()
     assert 'upsampler.0.weight' not in sd
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/unimatch'), reason='needs the reference checkout (build container only)')
+@pytest.mark.parametrize('name', sorted(CONFIGS))
+def test_constructor_weights_match_reference_seed_326(name):
+    """SURVEY.md 8(d) prescribes the weights ``torch.manual_seed(326)`` (main_flow.py:56) + the reference constructor.  This
+    package's constructor registers and initialises its parameters in the same order with the same initialisers, so the same seed
+    gives BIT-IDENTICAL weights -- which is what lets the GPU box (no reference there) rebuild the reference-constructor
+    weight set (tools/parity_fullsize.py, weight set ``ctor326``)."""
+    sys.path.insert(0, '/root/reference')
+    try:
+        from unimatch.unimatch import UniMatch as RefUniMatch
+    finally:
+        sys.path.remove('/root/reference')
+    ck = CONFIGS[name][0]
+    torch.manual_seed(326)
+    ref = RefUniMatch(**ck).state_dict()
+    torch.manual_seed(326)
+    own = UniMatch(**ck).state_dict()
+    assert list(ref) == list(own)
+    for k in ref:
+        assert torch.equal(ref[k], own[k]), k
 
 
 def test_reference_error_behaviour():

@@ -25,7 +25,12 @@ if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply windo
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcw.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmcw -name '*counter_collection.csv' | head -1)
 if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv > "$OUT/${TAG}_pmc_write.json"; fi
-# then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json
+(cd /tmp && timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY \
+    --kernel-trace --output-format csv -d /tmp/${TAG}_pmcs -o p -- \
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcs.log" 2>&1 < /dev/null)
+PMC=$(find /tmp/${TAG}_pmcs -name '*counter_collection.csv' | head -1)
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_kernel > "$OUT/${TAG}_pmc_sq.json"; fi
+# then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_pmc_sq.json
 timeout 150 python tools/bench_configs.py --steps 10 2>&1 | grep cfg > "$OUT/${TAG}_all_configs.txt"
 (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_cfg4" -o p -- \
     python "$R/tools/profile_config.py" gmflow_s2_rr6 4 512 768 > "$OUT/${TAG}_cfg4.log" 2>&1 < /dev/null)

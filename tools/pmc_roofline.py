@@ -3,7 +3,10 @@ bench.py) into profiles/pmc_current.json: corrected HBM bytes per launch of the 
 the kernel sources and the git commit they were measured at.  bench.py quotes `roofline.traffic` from that file and nulls it
 when the stamp no longer matches the tree.  Run in the build container after the GPU call:
 
-    python tools/pmc_roofline.py gpurun_out/r02_pmc_fetch.json gpurun_out/r02_pmc_write.json [--from-r01]
+    python tools/pmc_roofline.py gpurun_out/rNN_pmc_fetch.json gpurun_out/rNN_pmc_write.json [gpurun_out/rNN_pmc_sq.json]
+
+The optional third file is an SQ pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, ...) of the same command: it adds `mfma_busy` =
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per kernel, which bench.py quotes beside `frac`.
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte requests as 64 bytes -> read bytes =
 2 x FETCH_SIZE(KiB) x 1024 for the wide coalesced rows these kernels stream; WRITE_SIZE(KiB) x 1024 as is.
@@ -17,8 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import PMC_FILE, source_stamp  # noqa: E402
 
-KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv_kernel': ['global_match.hip', 'common.h'],
-           'gsv3_kernel': ['global_match.hip', 'common.h'], 'gsv4_kernel': ['global_match.hip', 'common.h']}
+KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv3_kernel': ['global_match.hip', 'common.h'],
+           'gsv4_kernel': ['global_match.hip', 'common.h'], 'ffn_kernel': ['ffn.hip', 'common.h']}
+NUM_SIMDS, NUM_XCDS = 1024, 8
 
 
 def main():
@@ -38,7 +42,9 @@ def main():
                           'WRITE_SIZE_KiB': v['WRITE_SIZE_KiB'], 'source_stamp': source_stamp(KERNELS[base]),
                           'from': 'profiles/r01_pmc_final.json'}
     else:
-        fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+        files = [a for a in sys.argv[1:] if not a.startswith('--')]
+        fetch, write = json.load(open(files[0])), json.load(open(files[1]))
+        sq = json.load(open(files[2])) if len(files) > 2 else {}
         for k, v in fetch.items():
             base = k.split('<')[0]
             if base not in KERNELS or 'FETCH_SIZE' not in v:
@@ -48,6 +54,12 @@ def main():
             out[k] = {'hbm_traffic_bytes_per_launch': int(2 * f * 1024 + w * 1024), 'FETCH_SIZE_KiB': round(f, 1),
                       'WRITE_SIZE_KiB': round(w, 1), 'dispatches_sampled': v['FETCH_SIZE']['dispatches'],
                       'source_stamp': source_stamp(KERNELS[base])}
+            c = sq.get(k, {})
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
+                busy, gui = c['SQ_VALU_MFMA_BUSY_CYCLES']['mean'], c['GRBM_GUI_ACTIVE']['mean']
+                out[k].update({'mfma_busy': round(busy / (NUM_SIMDS * gui / NUM_XCDS), 4), 'SQ_VALU_MFMA_BUSY_CYCLES': busy,
+                               'GRBM_GUI_ACTIVE': gui,
+                               **{n: v['mean'] for n, v in c.items() if n not in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')}})
     json.dump(out, open(PMC_FILE, 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
