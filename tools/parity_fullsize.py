@@ -84,7 +84,21 @@ def _slice_kw(kw, lo, hi):
 
 def cpu_task(task):
     """One sample's CPU legs (runs in a worker process): fp64 truth and the fp32 port's distance to it."""
-    cfg, which, kind, seed, idx, threads = task
+    cfg, which, kind, seed, idx, threads = task[:6]
+    cache = task[6] if len(task) > 6 else None
+    path = os.path.join(cache, 'cfg{}_{}_{}_{}_{}.pt'.format(*task[:5])) if cache else None
+    if path and os.path.exists(path):
+        return task[:5], torch.load(path)
+    key, rec = _cpu_task(cfg, which, kind, seed, idx, threads)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        torch.save(rec, path + '.tmp')
+        os.replace(path + '.tmp', path)
+    return key, rec
+
+
+def _cpu_task(cfg, which, kind, seed, idx, threads):
+    task = (cfg, which, kind, seed, idx)
     torch.set_num_threads(threads)
     from oracle import model as om
     ck, kw, i0, i1 = case_inputs(cfg, kind, seed)
@@ -104,7 +118,8 @@ class CpuLegs:
     """Worker pool for the CPU legs.  ``submit`` queues samples (longest configs first), ``get`` waits for one."""
     COST = {4: 80, 3: 52, 2: 5, 5: 3.3, 1: 2}
 
-    def __init__(self, workers=None, threads=None):
+    def __init__(self, workers=None, threads=None, cache=None):
+        self.cache = cache                       # directory: CPU legs survive across runs of the tool (A/B of library builds)
         ncpu = os.cpu_count() or 8
         self.threads = threads or min(16, ncpu)
         self.workers = workers or max(1, min(12, ncpu // self.threads))
@@ -117,7 +132,7 @@ class CpuLegs:
             self.pool = mp.get_context('spawn').Pool(self.workers)
         for key in sorted(set(keys), key=lambda k: -self.COST.get(k[0], 1)):
             if key not in self.pending and key not in self.done:
-                self.pending[key] = self.pool.apply_async(cpu_task, (tuple(key) + (self.threads,),))
+                self.pending[key] = self.pool.apply_async(cpu_task, (tuple(key) + (self.threads, self.cache),))
 
     def get(self, key):
         key = tuple(key)
@@ -217,9 +232,10 @@ def main():
     ap.add_argument('--workers', type=int, default=None)
     ap.add_argument('--threads', type=int, default=None)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--cache', default=None, help='directory for the CPU legs (reused by later runs, e.g. other library builds)')
     a = ap.parse_args()
     cfgs = [int(c) for c in a.configs.split(',')]
-    legs = CpuLegs(a.workers, a.threads)
+    legs = CpuLegs(a.workers, a.threads, a.cache)
     cases = [(cfg, which, kind, 1000 + 17 * s) for cfg in cfgs for which in a.weights.split(',') for kind in a.kinds.split(',')
              for s in range(a.seeds) if which == 'conditioned' or cfg in ONE_SCALE or a.chaotic]
     nb = lambda cfg: RUNS[cfg][3] if a.batch == 'config' else 1

@@ -15,7 +15,8 @@ SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', '
            'rccl_gather.hip', 'local_corr_mfma.hip', 'aliases.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
 # per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
-EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize'], 'window_attn.hip': ['-fno-slp-vectorize'],
+               'linear.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 
@@ -57,5 +58,29 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines, verbose=False):
+    """A diagnostic build ``unimatch_amd/_variants/lib<name>.so`` of the whole library with extra ``-D`` flags (A/B switches
+    behind -DUM_DEBUG_SWITCHES, precision-budget experiments ...); load it with ``UM_LIB=<path>`` (tools/ab_bench.py)."""
+    hipcc = find_hipcc()
+    objdir = os.path.join(HERE, '_variants', '_obj_' + name)
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + ['-c', os.path.join(CSRC, src), '-o', o]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        objs.append(o)
+    lib = os.path.join(HERE, '_variants', f'lib{name}.so')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-ldl'], check=True)
+    shutil.rmtree(objdir, ignore_errors=True)
+    return lib
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--variant' in sys.argv:            # python -m unimatch_amd.build --variant NAME -DFOO=1 -DBAR
+        i = sys.argv.index('--variant')
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith('-D')], verbose=True))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

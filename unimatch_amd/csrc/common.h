@@ -65,6 +65,15 @@ struct Fp16 {
         f16x2 h = __builtin_bit_cast(f16x2, u);
         return __builtin_convertvector(h, f32x2);
     }
+    // lo plane of a pair: rn16(p - hi), hi = pack2(p0, p1).  `neg1` must be um_opaque_neg1(): fma(float(hi), -1, p) with a -1
+    // the compiler cannot see selects v_fma_mixlo_f16 + v_fma_mixhi_f16 (the fp16 -> fp32 extension rides inside the
+    // instruction), 2 VALU per pair; the literal form folds to a subtraction and costs 2 v_cvt_f32_f16 + 2 v_sub (or one
+    // v_pk_add_f32) + v_cvt_pk_f16_f32.  Same bits either way: p - hi is exact in fp32.  Needs -fno-slp-vectorize (build.py).
+    static __device__ __forceinline__ unsigned lo2(float p0, float p1, unsigned hi, float neg1) {
+        const f16x2 h = __builtin_bit_cast(f16x2, hi);
+        const f16x2 l = {(_Float16)__builtin_fmaf((float)h[0], neg1, p0), (_Float16)__builtin_fmaf((float)h[1], neg1, p1)};
+        return __builtin_bit_cast(unsigned, l);
+    }
     static __device__ __forceinline__ f32x16 mfma(i16x8 a, i16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
                                                       __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -88,11 +97,22 @@ struct Bf16 {
         f32x2 r = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
         return r;
     }
+    static __device__ __forceinline__ unsigned lo2(float p0, float p1, unsigned hi, float neg1) {   // (unused: one bf16 plane)
+        const f32x2 hh = unpack2(hi);
+        return pack2(__builtin_fmaf(hh[0], neg1, p0), __builtin_fmaf(hh[1], neg1, p1));
+    }
     static __device__ __forceinline__ f32x16 mfma(i16x8 a, i16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                        __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+
+// -1.0f in an SGPR whose value the compiler cannot see (see Fp16::lo2)
+__device__ __forceinline__ float um_opaque_neg1() {
+    float v = -1.0f;
+    asm volatile("" : "+s"(v));
+    return v;
+}
 
 // ---- MFMA 32x32x16 fragment conventions (wave64) ---------------------------------------------
 //   A (32 x 16): lane l holds A[m = l & 31][k = 8 * (l >> 5) + j], j = 0..7   (16 contiguous bytes)

@@ -25,6 +25,11 @@
 // fp32 accumulation (exact mode); bf16, one product (fast mode).  Weights are pre-scaled by 2^wshift.
 #include <type_traits>
 #include <stdlib.h>
+// -DUM_FFN_H1=1 (diagnostic builds: profiles/r03_precision_budget.txt): the second GEMM with gelu(H) in ONE fp16 plane
+// (W2_lo.H + W2_hi.H: 2 products instead of 3, no lo split of the hidden activations).
+#ifndef UM_FFN_H1
+#define UM_FFN_H1 0
+#endif
 #include "common.h"
 #include "planes.h"
 
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const float neg1 = um_opaque_neg1();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wave & 3, role = wave >> 2;                 // partners w, w ^ 4 sit on the same SIMD
     const int half = lane >> 5, tl = lane & 31;
@@ -179,9 +185,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
             xf[0][ks] = __builtin_bit_cast(i16x8, h);
             if (NS == 2) {
-                const f32x2 u0 = T::unpack2(h[0]), u1 = T::unpack2(h[1]), u2 = T::unpack2(h[2]), u3 = T::unpack2(h[3]);
-                const u32x4 l = {T::pack2(v0[0] - u0[0], v0[1] - u0[1]), T::pack2(v0[2] - u1[0], v0[3] - u1[1]),
-                                 T::pack2(v1[0] - u2[0], v1[1] - u2[1]), T::pack2(v1[2] - u3[0], v1[3] - u3[1])};
+                const u32x4 l = {T::lo2(v0[0], v0[1], h[0], neg1), T::lo2(v0[2], v0[3], h[1], neg1),
+                                 T::lo2(v1[0], v1[1], h[2], neg1), T::lo2(v1[2], v1[3], h[3], neg1)};
                 xf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
             }
         }
@@ -264,7 +269,6 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     // H^T operand fragments of the wave's 16 hidden units (one k-step), built in four stages from the GELU outputs
     struct Frag {
         unsigned wh[4], wl[4];
-        f32x2 u[4];
     };
     auto frag_stage = [&](Frag& f, const Gelu2* g, i16x8* pf, int stage) {
         switch (stage) {
@@ -272,16 +276,16 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) f.wh[q] = T::pack2(g[q].x[0], g[q].x[1]);
             break;
-        case 1:
-            if (NS == 2) {
+        case 1:                                  // lo plane: 2 x (v_fma_mixlo_f16 + v_fma_mixhi_f16) per stage (Fp16::lo2)
+            if (NS == 2 && !UM_FFN_H1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f.u[q] = T::unpack2(f.wh[q]);
+                for (int q = 0; q < 2; ++q) f.wl[q] = T::lo2(g[q].x[0], g[q].x[1], f.wh[q], neg1);
             }
             break;
         case 2:
-            if (NS == 2) {
+            if (NS == 2 && !UM_FFN_H1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f.wl[q] = T::pack2(g[q].x[0] - f.u[q][0], g[q].x[1] - f.u[q][1]);
+                for (int q = 2; q < 4; ++q) f.wl[q] = T::lo2(g[q].x[0], g[q].x[1], f.wh[q], neg1);
             }
             break;
         default: {
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             const auto sy = __builtin_amdgcn_permlane32_swap(f.wh[1], f.wh[3], false, false);
             const u32x4 fh = {sx[0], sy[0], sx[1], sy[1]};
             pf[0] = __builtin_bit_cast(i16x8, fh);
-            if (NS == 2) {
+            if (NS == 2 && !UM_FFN_H1) {
                 const auto tx = __builtin_amdgcn_permlane32_swap(f.wl[0], f.wl[2], false, false);
                 const auto ty = __builtin_amdgcn_permlane32_swap(f.wl[1], f.wl[3], false, false);
                 const u32x4 fl = {tx[0], ty[0], tx[1], ty[1]};
@@ -310,7 +314,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         constexpr bool HAS_A = decltype(has_a_tag)::value && !(UM_FFN_ABL & 4);
         constexpr bool HAS_B = decltype(has_b_tag)::value && !(UM_FFN_ABL & 8);
         constexpr int MF = (NS == 2) ? 3 : 1;
-        constexpr int NMFMA = (HAS_A ? 8 * MF : 0) + (HAS_B ? 4 * MF : 0);
+        constexpr int MFB = (NS == 2 && UM_FFN_H1) ? 2 : MF;       // products of phase B (see UM_FFN_H1)
+        constexpr int NMFMA = (HAS_A ? 8 * MF : 0) + (HAS_B ? 4 * MFB : 0);
         constexpr int NGELU = 4 * UM_GELU_STAGES, NSTAGE = NGELU + 4;
         const int slot = i & 1;
         const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
@@ -369,11 +374,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 if (NS == 2) vl[ot] = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
             }
 #pragma unroll
-            for (int m = 0; m < MF; ++m)
+            for (int m = 0; m < MFB; ++m)
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) {
                     const i16x8 wa = (NS == 2 && m == 0) ? vl[ot] : vh[ot];
-                    const i16x8 hb = (NS == 2 && m == 1) ? pf[NS - 1] : pf[0];
+                    const i16x8 hb = (NS == 2 && MFB == 3 && m == 1) ? pf[NS - 1] : pf[0];
                     o[ot] = T::mfma(wa, hb, o[ot]);
                     valu_share(mslot++);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 if (NS == 2) {
                     const i16x8 vl = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
                     o[ot] = T::mfma(vl, pf[0], o[ot]);
-                    o[ot] = T::mfma(vh, pf[NS - 1], o[ot]);
+                    if (!UM_FFN_H1) o[ot] = T::mfma(vh, pf[NS - 1], o[ot]);
                 }
                 o[ot] = T::mfma(vh, pf[0], o[ot]);
             }

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const float neg1 = um_opaque_neg1();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     // 1-D XCD-aware grid: the n tiles of one token tile are neighbours on ONE XCD, so the second reads the activation tile
@@ -119,9 +120,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
             unsigned char* p = dst + r * 64 + (((f4 >> 1) ^ ((r >> 2) & 3)) << 4) + (f4 & 1) * 8;
             *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
             if (NS == 2) {
-                const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                const unsigned l0 = T::pack2(areg[i][0] - u0[0], areg[i][1] - u0[1]);
-                const unsigned l1 = T::pack2(areg[i][2] - u1[0], areg[i][3] - u1[1]);
+                const unsigned l0 = T::lo2(areg[i][0], areg[i][1], h0, neg1), l1 = T::lo2(areg[i][2], areg[i][3], h1, neg1);
                 *reinterpret_cast<u32x2*>(p + TILE) = u32x2{l0, l1};
             }
         }
@@ -234,9 +233,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
                 const unsigned h0 = T::pack2(v[0], v[1]), h1 = T::pack2(v[2], v[3]);
                 *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
                 if (NS == 2) {
-                    const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                    const unsigned l0 = T::pack2(v[0] - u0[0], v[1] - u0[1]);
-                    const unsigned l1 = T::pack2(v[2] - u1[0], v[3] - u1[1]);
+                    const unsigned l0 = T::lo2(v[0], v[1], h0, neg1), l1 = T::lo2(v[2], v[3], h1, neg1);
                     *reinterpret_cast<u32x2*>(p + 32768) = u32x2{l0, l1};
                 }
             }

@@ -37,6 +37,13 @@ __device__ unsigned long long* g_um_trace = nullptr;
 #define UM_STAMP(slot) do { } while (0)
 #endif
 
+// -DUM_WATTN_P1=1 (diagnostic builds: profiles/r03_precision_budget.txt): the PV product with P in ONE fp16 plane -- 2 MFMA
+// products (V_lo.P + V_hi.P) instead of 3, no lo split of P -- and the softmax denominator summed over the SAME rounded
+// probabilities (v_dot2c_f32_f16), so that the result is an exact weighted mean with weights perturbed by <= 2^-11 relative.
+#ifndef UM_WATTN_P1
+#define UM_WATTN_P1 0
+#endif
+
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
     const unsigned short* kp;
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
+    const float neg1 = um_opaque_neg1();
     // KSPLIT: a launch with few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking the whole window) is latency-
     // bound by that walk.  `split` workgroups share a query tile, neighbours in the grid (same XCD); part p takes the p-th
     // share of the key tiles; parts > 0 leave (O^T, M, l) in a memory slot and raise its flag, part 0 merges them (integer
@@ -219,10 +227,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     hi[j] = T::pack2(y[2 * j], y[2 * j + 1]);
-                    if (NS == 2) {
-                        const f32x2 hh = T::unpack2(hi[j]);
-                        lo[j] = T::pack2(y[2 * j] - hh[0], y[2 * j + 1] - hh[1]);
-                    }
+                    if (NS == 2) lo[j] = T::lo2(y[2 * j], y[2 * j + 1], hi[j], neg1);
                 }
                 xf[0][ks] = __builtin_bit_cast(i16x8, hi);
                 if (NS == 2) xf[NS - 1][ks] = __builtin_bit_cast(i16x8, lo);
@@ -254,10 +259,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int j = 0; j < 4; ++j) {
                     const float p0 = acc[8 * kk + 2 * j] * a.wm_scale, p1 = acc[8 * kk + 2 * j + 1] * a.wm_scale;
                     wh[j] = T::pack2(p0, p1);
-                    if (NS == 2) {
-                        const f32x2 hh = T::unpack2(wh[j]);
-                        wl[j] = T::pack2(p0 - hh[0], p1 - hh[1]);
-                    }
+                    if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
                 }
                 {
                     const auto xx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
@@ -370,8 +372,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         advance(bly, blx);
     };
     // one statement = the wave's two 4-row groups of one plane of K (or V): ONE M0 write, the second request carries the LDS
-    // (and global) displacement of 1024 bytes in its instruction offset, so its source comes in 1024 bytes low.  No M0 save /
-    // restore: hipcc keeps nothing in M0 in this kernel's loop.  4 instructions per pair instead of 10.
+    // (and global) displacement of 1024 bytes in its instruction offset, so its source comes in 1024 bytes low.  M0 is saved and
+    // restored inside the statement (hipcc manages M0 itself for the prologue's / epilogue's lds_dma16 and does not honour an
+    // "m0" clobber): 6 instructions per pair instead of 10.
     constexpr int NPAIR = 2 * NS;
     auto stage_pair = [&](int ip, unsigned char* base) {        // ip = 0 .. NPAIR-1, compile-time after unrolling
         const int pl = ip >> 1, isv = ip & 1;
@@ -379,8 +382,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
         const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024"
-                     : : "v"(s0), "v"(s1), "s"(dst) : "memory", "m0");
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
     };
 
     const int li = lane & 15, lg = (lane >> 4) & 1;
@@ -492,12 +497,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= resc;
         }
+        constexpr bool P1 = (NS == 2) && UM_WATTN_P1;           // one P plane (see UM_WATTN_P1)
+        constexpr int NSP = P1 ? 1 : NS;
         const float mc = M + (float)PSHIFT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = fast_exp2(__builtin_fmaf(sc[r], c, mc));
             sc[r] = p;
-            l += p;
+            if (!P1) l += p;
         }
 
         // ---- P^T operand fragments: cvt + v_permlane32_swap, no LDS ---------------------------------------
@@ -512,9 +519,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int j = 0; j < 4; ++j) {
                 const float p0 = sc[r0 + 2 * j], p1 = sc[r0 + 2 * j + 1];
                 wh[j] = T::pack2(p0, p1);
-                if (NS == 2) {
-                    const f32x2 hh = T::unpack2(wh[j]);
-                    wl[j] = T::pack2(p0 - hh[0], p1 - hh[1]);
+                if (NSP == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
+                if constexpr (P1) {
+                    const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
+                    l = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wh[j]), one, l, false);
                 }
             }
             {
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const u32x4 f = {x[0], y[0], x[1], y[1]};
                 pf[0][ks] = __builtin_bit_cast(i16x8, f);
             }
-            if (NS == 2) {
+            if (NSP == 2) {
                 const auto x = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
                 const auto y = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
                 const u32x4 f = {x[0], y[0], x[1], y[1]};
@@ -555,13 +563,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                         (__attribute__((address_space(3))) i16x4*)(va + PLANE + 4 * 256));
                     vl = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
-                    o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
+                    if (NSP == 2) o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
                 }
                 o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
             }
         }
         {   // transpose reads two (k-step, d-tile) groups ahead of the MFMAs
-            constexpr int RD = 2 * NS, MF = (NS == 2) ? 3 : 1;
+            constexpr int RD = 2 * NS, MF = NS + NSP - 1;
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 1);
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
@@ -675,10 +683,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int j = 0; j < 4; ++j) {
             const float p0 = o[dt][r0 + 2 * j] * inv, p1 = o[dt][r0 + 2 * j + 1] * inv;
             wh[j] = T::pack2(p0, p1);
-            if (NS == 2) {
-                const f32x2 hh = T::unpack2(wh[j]);
-                wl[j] = T::pack2(p0 - hh[0], p1 - hh[1]);
-            }
+            if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
         }
         {
             const auto x = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
