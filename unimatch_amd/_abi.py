@@ -33,6 +33,7 @@ SIGNATURES = {
     'um_window_attn_qproj_merge_fwd': (_c_int, [_c_void_p] * 8 + [ctypes.c_float, _c_int, _c_void_p] + [_c_int] * 5 + [ctypes.c_long] +
                                        [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_window_attn_ksplit_workspace_bytes': (_c_size_t, [_c_int] * 5),
+    'um_window_attn_plan': (_c_int, [_c_int] * 5 + [ctypes.POINTER(_c_int)] * 3),
     'um_planes_bytes': (_c_size_t, [ctypes.c_long, _c_int, _c_int]),
     'um_weight_planes': (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p]),
     'um_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_float, _c_int, _c_void_p]),

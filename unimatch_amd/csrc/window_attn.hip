@@ -71,9 +71,11 @@ struct WattnArgs {
     // QPROJ variant: q = x . Wq^T computed in the prologue (transformer.py:58); qp is unused
     const float* x;              // [S][L][128] fp32 source tokens
     const unsigned short* wq;    // planes [NS][128][128] of the query weight, pre-scaled by 2^wshift (stride wm_plane_stride)
-    // KSPLIT variant (small launches): `split` workgroups per query tile, each on 1 / split of the window's key tiles
+    // KSPLIT variant (small launches and the remainder round of big ones): `split` workgroups per query tile, each on 1 / split
+    // of the window's key tiles; tile_base = first query tile of this launch (a call may be two launches, see wattn_plan)
     int split;
-    float* ks_part;              // [total * (split - 1)][66][256] fp32: O^T (64 registers), M, l of the parts 1 .. split-1
+    int tile_base;
+    float* ks_part;              // [tiles * (split - 1)][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of the parts 1 .. split-1
     unsigned* ks_flag;           // [total * (split - 1)], zero between launches: 1 = the slot is complete
 };
 
@@ -133,8 +135,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // (the host only splits while total * split fits), so the wait cannot deadlock.
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
     const int nsplit = KSPLIT ? a.split : 1;
-    const int wg = KSPLIT ? wgid / nsplit : wgid;
-    const int part = KSPLIT ? wgid - wg * nsplit : 0;
+    const int wl = KSPLIT ? wgid / nsplit : wgid;                  // query tile within this launch (indexes the hand-off slots)
+    const int part = KSPLIT ? wgid - wl * nsplit : 0;
+    const int wg = wl + a.tile_base;                               // query tile of the call
     const int qt = wg % a.nqt;
     const int win = (wg / a.nqt) % a.nwin;
     const int s = wg / (a.nqt * a.nwin);
@@ -593,42 +596,52 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // The slots are written and read ONLY by agent-scope accesses, which go through to memory themselves; a release /
         // acquire FENCE at agent scope would write back / invalidate the XCD's whole L2 (measured).  What is needed is the
         // completion of the stores before the flag is raised: vmcnt(0) + the barrier.
+        // Slot layout: 17 vectors of 16 bytes per thread, [vector][thread] -- O^T (16 vectors: tile dt, register group g) then
+        // (M, l, -, -).
+        constexpr int KS_SLOT = 17 * 256 * 4;                        // floats per slot
         if (part > 0) {
-            const long slot = (long)wg * (nsplit - 1) + part - 1;
-            float* pr = a.ks_part + slot * (66 * 256) + tid;
+            const long slot = (long)wl * (nsplit - 1) + part - 1;
+            float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __hip_atomic_store(pr + (dt * 16 + r) * 256, o[dt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pr + 64 * 256, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pr + 65 * 256, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    st_agent_16B(pr + (dt * 4 + g) * 1024, v);
+                }
+            {
+                const f32x4 v = {M, l, 0.f, 0.f};
+                st_agent_16B(pr + 16 * 1024, v);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         for (int p = 1; p < nsplit; ++p) {
-            const long slot = (long)wg * (nsplit - 1) + p - 1;
+            const long slot = (long)wl * (nsplit - 1) + p - 1;
             if (tid == 0) {
                 while (__hip_atomic_load(a.ks_flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
                     __builtin_amdgcn_s_sleep(4);
             }
             __syncthreads();
-            const float* pr = a.ks_part + slot * (66 * 256) + tid;
-            const float Mo = __hip_atomic_load(pr + 64 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float lo = __hip_atomic_load(pr + 65 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
+            const f32x4 ml = ld_agent_16B(pr + 16 * 1024);
+            const float Mo = ml[0], lo = ml[1];
             const float Ms = fminf(M, Mo);                           // offsets are integers: the factors are powers of two
             const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
             l = l * fa + lo * fb;
             M = Ms;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 w[4];
+                const float* q = pr + dt * 4 * 1024;
+                ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float oo = __hip_atomic_load(pr + (dt * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    o[dt][r] = o[dt][r] * fa + oo * fb;
-                }
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[dt][4 * g + i] = o[dt][4 * g + i] * fa + w[g][i] * fb;
+            }
             __syncthreads();                                         // everybody has read the slot
             if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         }
@@ -787,7 +800,7 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
 static int wattn_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 static int wattn_key_split(int total, int ntiles) {
-    static const bool off = um_debug_env("UM_WATTN_NO_KSPLIT") != nullptr;      // A/B switch
+    static const bool off = um_debug_env("UM_WATTN_NO_KSPLIT") != nullptr;      // A/B switch (diagnostic builds)
     if (off) return 1;
     const int cus = wattn_num_cus();
     int split = 1;
@@ -796,16 +809,59 @@ static int wattn_key_split(int total, int ntiles) {
     return split;
 }
 
-static size_t wattn_ks_bytes(int total, int split) {
-    const size_t slots = (size_t)total * (split - 1);
-    return align256w(slots * sizeof(unsigned)) + slots * (66 * 256 * sizeof(float));
+// ---- launch plan: a pure function of the geometry (and the device's CU count).
+// The chip holds 2 * CUs workgroups at once.  A call of `total` query tiles is
+//   * a small launch (total <= slots): every tile key-split `split` ways while the launch stays resident (batch-1 latency);
+//   * whole rounds: tiles [0, full) one workgroup each, and -- when the last round would be partial -- the REMAINDER
+//     tiles [full, total) key-split so that they fill (up to a power of two) one round of their own, as a second launch:
+//     config 2 at batch 8 is 768 tiles on 512 slots = 1.5 rounds; the half-empty round ran one wave per SIMD for a whole
+//     tile walk (11 - 14 % of the kernel, profiles/r02_attn_streamk_attempt.txt); as 512 tiles + 256 tiles x 2 parts both
+//     launches are full rounds and the second is half as long.  Parts meet through the KSPLIT hand-off (same code, same
+//     workspace contract), in a launch of their own so that every part is resident (<= slots workgroups).
+struct WattnPlan {
+    int full;       // tiles served one workgroup each (first launch; 0: none)
+    int rem;        // tiles served key-split (second launch, or the only one; 0: none)
+    int split;      // parts per tile of the key-split launch (1 when rem == 0)
+};
+
+static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
+    const int slots = 2 * wattn_num_cus();
+    if (!can_split) return {total, 0, 1};
+    if (total <= slots) {
+        const int split = wattn_key_split(total, ntiles);
+        return split > 1 ? WattnPlan{0, total, split} : WattnPlan{total, 0, 1};
+    }
+    static const bool off = um_debug_env("UM_WATTN_NO_BALANCE") != nullptr;     // A/B switch (diagnostic builds)
+    const int rem = total % slots;
+    if (off || rem == 0) return {total, 0, 1};
+    int k = 1;
+    while (k < 4 && rem * (2 * k) <= slots && ntiles >= 4 * (2 * k)) k *= 2;
+    if (k == 1) return {total, 0, 1};
+    return {total - rem, rem, k};
+}
+
+static size_t wattn_ks_bytes(int tiles, int split) {
+    const size_t slots = (size_t)tiles * (split - 1);
+    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));
 }
 
 extern "C" size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w) {
     if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w) return 0;
     const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
-    const int split = wattn_key_split(total, (n + 31) / 32);
-    return split > 1 ? wattn_ks_bytes(total, split) : 0;
+    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
+    return p.rem > 0 ? wattn_ks_bytes(p.rem, p.split) : 0;
+}
+
+// launch plan of um_window_attn_qproj_merge_fwd for a geometry: tiles served whole / tiles served key-split / parts per split tile
+extern "C" int um_window_attn_plan(int streams, int h, int w, int win_h, int win_w, int* full_tiles, int* split_tiles, int* parts) {
+    if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w || !full_tiles || !split_tiles || !parts)
+        return UM_ERR_BAD_ARG;
+    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
+    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
+    *full_tiles = p.full;
+    *split_tiles = p.rem;
+    *parts = p.split;
+    return 0;
 }
 
 static int check_attn_geometry(int streams, int h, int w, int channels, int win_h, int win_w, int shift_h, int shift_w,
@@ -969,27 +1025,36 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     static const float headroom = [] { const char* e = um_debug_env("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
-    if (wm && wq && ks_ws) {
-        const int split = wattn_key_split(a.total, (a.n + 31) / 32);
-        if (split > 1 && ks_ws_bytes >= wattn_ks_bytes(a.total, split)) {
-            a.split = split;
-            a.ks_flag = (unsigned*)ks_ws;
-            a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)a.total * (split - 1) * sizeof(unsigned)));
-        }
-    }
+    a.tile_base = 0;
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
-    um_census_hit(a.split > 1 ? UM_V_WATTN_KSPLIT : UM_V_WATTN_TILE);
-    if (wm && wq && a.split > 1) {
-        if (mode == 0)
-            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(a.total * a.split), dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, true>), dim3(a.total * a.split), dim3(256), 0, stream, a);
-    } else if (wm && wq) {
-        if (mode == 0)
-            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true>), dim3(a.total), dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true>), dim3(a.total), dim3(256), 0, stream, a);
-    } else if (wm) {
+    if (wm && wq) {
+        // the layer kernel (query projection + attention + merge + LayerNorm): whole rounds one workgroup per tile, small
+        // launches and the remainder round key-split (wattn_plan); without workspace everything runs one workgroup per tile
+        WattnPlan p = wattn_plan(a.total, (a.n + 31) / 32, ks_ws != nullptr);
+        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1};
+        if (p.full > 0) {
+            um_census_hit(UM_V_WATTN_TILE);
+            if (mode == 0)
+                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true>), dim3(p.full), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true>), dim3(p.full), dim3(256), 0, stream, a);
+            if (hipError_t e = hipGetLastError()) return (int)e;
+        }
+        if (p.rem > 0) {
+            um_census_hit(UM_V_WATTN_KSPLIT);
+            a.tile_base = p.full;
+            a.split = p.split;
+            a.ks_flag = (unsigned*)ks_ws;
+            a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)p.rem * (p.split - 1) * sizeof(unsigned)));
+            if (mode == 0)
+                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(p.rem * p.split), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, true>), dim3(p.rem * p.split), dim3(256), 0, stream, a);
+        }
+        return (int)hipGetLastError();
+    }
+    um_census_hit(UM_V_WATTN_TILE);
+    if (wm) {
         if (mode == 0)
             hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true>), dim3(a.total), dim3(256), 0, stream, a);
         else
