@@ -246,17 +246,16 @@ def test_small_launch_split_plans_without_gpu():
     def hs_bytes(tiles, split):
         return ((tiles * (split - 1) * 4 + 255) // 256) * 256 + tiles * (split - 1) * slot_f
 
-    assert ks(16, 64, 96, 32, 48) == ks_bytes(256, 2)            # config 2, batch 8: 768 query tiles = 512 whole + 256 split in 2
+    assert ks(16, 64, 96, 32, 48) == 0                           # config 2, batch 8: 768 query tiles, one workgroup each
 
     def plan(*geo):
         f, r, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         assert lib.um_window_attn_plan(*geo, ctypes.byref(f), ctypes.byref(r), ctypes.byref(k)) == 0
         return f.value, r.value, k.value
-    assert plan(16, 64, 96, 32, 48) == (512, 256, 2)             # 1.5 rounds -> one full round + a half-length full round
-    assert plan(8, 128, 192, 16, 24) == (1536, 0, 1)             # config 4 scale 1 (4 pairs): 3 whole rounds, nothing to balance
-    assert plan(32, 60, 80, 30, 40) == (1024, 256, 2)            # config 5, batch 16: 1280 tiles = 2 rounds + 256 x 2
+    big = plan(16, 64, 96, 32, 48)                               # config 2, batch 8: a big launch is never key-split
+    assert big[1:] == (0, 1) and big[0] in (768, 384)            # (384 = 256-query workgroups where the build enables them)
+    assert plan(8, 128, 192, 16, 24) == (1536, 0, 1)             # config 4 scale 1 (4 pairs): 384-token windows, 128-query tiles
     assert plan(2, 64, 96, 32, 48) == (0, 96, 4)                 # batch 1: small launch, every tile in 4 parts
-    assert plan(18, 64, 96, 32, 48) == (864, 0, 1)               # 864 tiles: a remainder of 352 cannot be doubled, one launch
     assert ks(2, 64, 96, 32, 48) == ks_bytes(96, 4)              # batch 1 at 512x768: 96 tiles x 48 key tiles -> 4 parts
     assert ks(4, 64, 96, 32, 48) == ks_bytes(192, 2)             # batch 2: 192 tiles -> 2 parts (4 would not be resident)
     assert ks(2, 40, 56, 20, 28) == ks_bytes(40, 4)              # config 1: 560-token windows, 18 key tiles -> 4 parts of >= 4

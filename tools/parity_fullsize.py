@@ -170,18 +170,15 @@ def gpu_case(cfg, which, kind, seed, precision='exact', samples=None):
 
 
 def check_census(cfg, nsamples, census):
-    """The kernels the bench times must be the ones that ran.  At batch >= 2 every config fills the chip: attention and FFN run
-    their one-workgroup-per-tile instantiations (attention additionally its key-split instantiation for the REMAINDER round of
-    um_window_attn_plan -- config 2 at batch 8: 512 tiles + 256 x 2 -- which is part of what bench.py times), the FFN is never
-    hidden-split, and the global layers (flow correlation, propagation) run on gsv4."""
+    """The kernels the bench times must be the ones that ran: at batch >= 2 every config fills the chip, so no launch may
+    take a small-launch split variant, and the global layers (flow correlation, propagation) run on gsv4."""
     problems = []
     if nsamples >= 2:
-        if census.get('ffn_hsplit'):
-            problems.append(f"ffn_hsplit={census['ffn_hsplit']}")
+        for k in ('wattn_ksplit', 'ffn_hsplit'):
+            if census.get(k):
+                problems.append(f'{k}={census[k]}')
         if not census.get('wattn_tile') or not census.get('ffn_tile'):
             problems.append('attention / FFN tile kernels did not run')
-        if census.get('wattn_ksplit', 0) > census.get('wattn_tile', 0):
-            problems.append('more key-split attention launches than whole-tile launches')
         if not census.get('gsv4'):
             problems.append('gsv4 did not run')
     return problems

@@ -43,6 +43,9 @@ __device__ unsigned long long* g_um_trace = nullptr;
 #ifndef UM_WATTN_P1
 #define UM_WATTN_P1 0
 #endif
+#ifndef UM_WATTN_W8_DEFAULT
+#define UM_WATTN_W8_DEFAULT 0       // 1: big launches of the layer kernel use 256-query (8-wave) workgroups, see wattn_plan
+#endif
 
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
@@ -109,11 +112,20 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
                  : "memory");
 }
 
-template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
+// WAVES = 4: workgroup = 128 queries, two workgroups per CU, 2-slot K/V ring (tile t+1 streams in while tile t is consumed).
+// WAVES = 8 (big launches of the layer kernel, see wattn_plan): workgroup = 256 queries, ONE workgroup per CU -- the same two waves
+// per SIMD, but both read the SAME staged tiles: half the LDS-DMA requests per wave and tile (4 instead of 8; their issue is
+// 60 - 185 cycles each beside MFMAs, MI355X_MICROARCH.md) and a 4-slot ring with the DMA running THREE tiles ahead, so that the
+// per-tile wait for the wave's own pieces (2-slot ring: ~350 cycles of exposed memory latency under load) finds them landed.
+template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
-    // table [4 query classes][TK].  Two buffers: tile t+1 streams in by LDS-DMA while tile t is consumed.
+    // table [4 query classes][TK].  NSLOT buffers: tiles t+1 .. t+DIST stream in by LDS-DMA while tile t is consumed.
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int QT = 32 * WAVES;                 // queries per workgroup
+    constexpr int NSLOT = (WAVES == 8) ? 4 : 2;
+    constexpr int DIST = NSLOT - 1;                // tiles the staging runs ahead
     constexpr int TK = 32;
     constexpr int PLANE = TK * 256;
     constexpr int BIAS_OFF = 2 * NS * PLANE;
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // + window-local token -> (global token << 2 | mask class), tabulated once per workgroup when the window has at most
     // TAB_BYTES / 4 tokens (rounded up to tiles): a tile's staging arithmetic is then two LDS reads instead of ~40 VALU
     constexpr int TAB_BYTES = 8192;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + TAB_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * BUF + TAB_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,12 +164,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if constexpr (QPROJ) {       // Wq -> the idle K/V ring, in flight while the token table is being built
         const int row4 = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 4 * (8 * wave + i) + row4;
+        for (int i = 0; i < 32 / WAVES; ++i) {
+            const int row = 4 * ((32 / WAVES) * wave + i) + row4;
             const int cw = pc ^ (row & 15);
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
+                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * ((32 / WAVES) * wave + i)) * 256);
         }
     }
     const int ntiles = (a.n + TK - 1) / TK;
@@ -170,10 +182,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
 
     const bool use_tab = ntiles * TK * 4 <= TAB_BYTES;                  // uniform
-    const unsigned* tab = reinterpret_cast<const unsigned*>(lds + 2 * BUF);
+    const unsigned* tab = reinterpret_cast<const unsigned*>(lds + NSLOT * BUF);
     if (use_tab) {
         const int ty0 = wy * a.win_h, tx0 = wx * a.win_w;
-        for (int tl = tid; tl < ntiles * TK; tl += 256) {
+        for (int tl = tid; tl < ntiles * TK; tl += THREADS) {
             int ly = tl / a.win_w;
             const int lx = tl - ly * a.win_w;
             ly = min(ly, a.win_h - 1);                                  // past the window's last token: any valid row (masked)
@@ -182,13 +194,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             oy = oy >= a.h ? oy - a.h : oy;
             ox = ox >= a.w ? ox - a.w : ox;
             const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
-            reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
+            reinterpret_cast<unsigned*>(lds + NSLOT * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
         }
         if (!QPROJ) __syncthreads();                                    // QPROJ: the prologue's barriers below cover it
     }
 
     // ---- this lane's query -----------------------------------------------------------------------
-    const int tq = qt * 128 + wave * 32 + (lane & 31);
+    const int tq = qt * QT + wave * 32 + (lane & 31);
     int clsq;
     const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
     // per-lane LDS read offsets of an A-operand row tile (K tile, Wm / Wq rows): loop invariant
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
 
     // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
-    // 8w..8w+7 of the tile (2 instructions per plane).  LDS chunk position cp of row r holds source chunk
+    // RPW w .. RPW w + RPW - 1 of the tile (RPW = 32 / WAVES: NJ = 2 instructions per plane with 4 waves, 1 with 8).  LDS chunk position cp of row r holds source chunk
     // cp ^ swz(r): swzK = r & 15 (A-fragment ds_read_b128 conflict free), swzV = (r & 3) << 2 (the 4 rows of a
     // ds_read_b64_tr_b16 group land in 4 different bank quarters).
     // The kernel is instruction-issue bound (rocprof + ablations, profiles/), so the per-tile addressing is kept
@@ -297,11 +309,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // TK tokens per tile with one add / compare / select each.
     const int adv_y = TK / a.win_w, adv_x = TK - adv_y * a.win_w;      // TK tokens = adv_y rows + adv_x columns
     const int y0 = wy * a.win_h, x0 = wx * a.win_w;
-    int sly[2], slx[2];                                                  // staged rows (j = 0, 1)
-    long ssrc_k[2], ssrc_v[2];                                           // lane-constant part of the source offsets
+    constexpr int RPW = TK / WAVES, NJ = RPW / 4;
+    int sly[NJ], slx[NJ];                                                // staged rows (j = 0 .. NJ-1)
+    long ssrc_k[NJ], ssrc_v[NJ];                                         // lane-constant part of the source offsets
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = t0 * TK + 8 * wave + 4 * j + ((lane >> 4) & 3);     // TK is a multiple of 16: row & 15 is tile-local
+    for (int j = 0; j < NJ; ++j) {
+        const int row = t0 * TK + RPW * wave + 4 * j + ((lane >> 4) & 3);   // TK is a multiple of 16: row & 15 is tile-local
         sly[j] = row / a.win_w;
         slx[j] = row - sly[j] * a.win_w;
         const int cp = lane & 15;
@@ -335,15 +348,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // instructions per wave queues up in the CU's single address unit (measured: ~1100 of ~5400 cycles per
     // tile); issued one per k-step of the QK^T loop instead, each piece hides under three MFMAs.
     constexpr int NPIECE = 4 * NS;
-    const unsigned short* spk[2];
-    const unsigned short* spv[2];
+    const unsigned short* spk[NJ];
+    const unsigned short* spv[NJ];
     auto stage_prepare = [&](int t, unsigned char* base) {
         // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
         const bool need = has_mask || (t + 1) * TK > a.n;
         if (use_tab) {
-            const unsigned* tp = tab + t * TK + 8 * wave + ((lane >> 4) & 3);
+            const unsigned* tp = tab + t * TK + RPW * wave + ((lane >> 4) & 3);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const long goff = (kvbase + (long)(tp[4 * j] >> 2)) * a.ldkv;
                 spk[j] = a.kp + goff + ssrc_k[j];
                 spv[j] = a.vp + goff + ssrc_v[j];
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             int cls;
             const int tok = token_at(sly[j], slx[j], cls);
             advance(sly[j], slx[j]);
@@ -382,13 +395,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto stage_pair = [&](int ip, unsigned char* base) {        // ip = 0 .. NPAIR-1, compile-time after unrolling
         const int pl = ip >> 1, isv = ip & 1;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(
-            base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
+            base + (RPW * wave) * 256 + (isv * NS + pl) * PLANE));
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
-        const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
+        if constexpr (NJ == 2) {
+            const unsigned short* s1 = (isv ? spv[NJ - 1] : spk[NJ - 1]) + pl * a.kv_plane_stride - 512;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
+        } else {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(s0), "s"(dst) : "memory");
+        }
     };
 
     const int li = lane & 15, lg = (lane >> 4) & 1;
@@ -401,9 +419,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             voff[dt] = rowb * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
     }
 
-    stage_prepare(t0, lds);
+    // prologue: tiles t0 .. t0 + DIST - 1 go into slots 0 .. DIST - 1 (tile t0 + d of the workgroup's walk lives in slot d % NSLOT)
 #pragma unroll
-    for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
+    for (int d = 0; d < DIST; ++d) {
+        if (t0 + d < t1) {
+            stage_prepare(t0 + d, lds + d * BUF);
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds + d * BUF);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -411,9 +435,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto tile = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         UM_STAMP(0);
-        const bool staging = t + 1 < t1;
-        unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
-        if (staging) stage_prepare(t + 1, nxt);
+        const bool staging = t + DIST < t1;
+        unsigned char* nxt = lds + ((SLOT + DIST) % NSLOT) * BUF;      // the slot tile t - 1 was read from
+        if (staging) stage_prepare(t + DIST, nxt);
         const unsigned char* kb = lds + SLOT * BUF;
         const unsigned char* vb = kb + NS * PLANE;
 
@@ -583,14 +607,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         __builtin_amdgcn_s_setprio(0);
         UM_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed in LDS
+        // this wave's share of tile t+1 has landed in LDS: with the DMA DIST tiles ahead only the pieces of tiles t+2 .. t+DIST
+        // (NPAIR * NJ each) may still be in flight -- they were issued a whole tile walk ago, the wait finds them done; the last
+        // DIST tiles of the walk issue nothing new and wait for everything
+        if (DIST > 1 && staging) asm volatile("s_waitcnt vmcnt(%0)" : : "n"((DIST - 1) * NPAIR * NJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UM_STAMP(5);
         __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
-    for (int t = t0; t < t1; t += 2) {
+    for (int t = t0; t < t1; t += NSLOT) {
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
+        if constexpr (NSLOT == 4) {
+            if (t + 2 < t1) tile(std::integral_constant<int, 2>{}, t + 2);
+            if (t + 3 < t1) tile(std::integral_constant<int, 3>{}, t + 3);
+        }
     }
     if constexpr (KSPLIT) {
         // The slots are written and read ONLY by agent-scope accesses, which go through to memory themselves; a release /
@@ -598,7 +630,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // completion of the stores before the flag is raised: vmcnt(0) + the barrier.
         // Slot layout: 17 vectors of 16 bytes per thread, [vector][thread] -- O^T (16 vectors: tile dt, register group g) then
         // (M, l, -, -).
-        constexpr int KS_SLOT = 17 * 256 * 4;                        // floats per slot
+        constexpr int KS_SLOT = 17 * THREADS * 4;                    // floats per slot
+        constexpr int KS_VEC = THREADS * 4;                          // floats per vector row
         if (part > 0) {
             const long slot = (long)wl * (nsplit - 1) + part - 1;
             float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
@@ -607,11 +640,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    st_agent_16B(pr + (dt * 4 + g) * 1024, v);
+                    st_agent_16B(pr + (dt * 4 + g) * KS_VEC, v);
                 }
             {
                 const f32x4 v = {M, l, 0.f, 0.f};
-                st_agent_16B(pr + 16 * 1024, v);
+                st_agent_16B(pr + 16 * KS_VEC, v);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -626,7 +659,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             __syncthreads();
             const float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
-            const f32x4 ml = ld_agent_16B(pr + 16 * 1024);
+            const f32x4 ml = ld_agent_16B(pr + 16 * KS_VEC);
             const float Mo = ml[0], lo = ml[1];
             const float Ms = fminf(M, Mo);                           // offsets are integers: the factors are powers of two
             const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
@@ -635,8 +668,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 w[4];
-                const float* q = pr + dt * 4 * 1024;
-                ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
+                const float* q = pr + dt * 4 * KS_VEC;
+                ld_agent_16Bx4(q, q + KS_VEC, q + 2 * KS_VEC, q + 3 * KS_VEC, w[0], w[1], w[2], w[3]);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -679,12 +712,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     {
         const int row4 = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 4 * (8 * wave + i) + row4;             // wave w stages rows 32 w .. 32 w + 31
+        for (int i = 0; i < 32 / WAVES; ++i) {
+            const int row = 4 * ((32 / WAVES) * wave + i) + row4;  // wave w stages 128 / WAVES rows
             const int c = pc ^ (row & 15);
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * c, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
+                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * c, lds + pl * 32768 + (4 * ((32 / WAVES) * wave + i)) * 256);
         }
     }
     i16x8 of[NS][8];
@@ -810,54 +843,51 @@ static int wattn_key_split(int total, int ntiles) {
 }
 
 // ---- launch plan: a pure function of the geometry (and the device's CU count).
-// The chip holds 2 * CUs workgroups at once.  A call of `total` query tiles is
-//   * a small launch (total <= slots): every tile key-split `split` ways while the launch stays resident (batch-1 latency);
-//   * whole rounds: tiles [0, full) one workgroup each, and -- when the last round would be partial -- the REMAINDER
-//     tiles [full, total) key-split so that they fill (up to a power of two) one round of their own, as a second launch:
-//     config 2 at batch 8 is 768 tiles on 512 slots = 1.5 rounds; the half-empty round ran one wave per SIMD for a whole
-//     tile walk (11 - 14 % of the kernel, profiles/r02_attn_streamk_attempt.txt); as 512 tiles + 256 tiles x 2 parts both
-//     launches are full rounds and the second is half as long.  Parts meet through the KSPLIT hand-off (same code, same
-//     workspace contract), in a launch of their own so that every part is resident (<= slots workgroups).
+//   * a small launch (every 128-query tile resident at once, two workgroups per CU): tiles key-split `split` ways while the
+//     launch stays resident (batch-1 latency);
+//   * a big launch: one workgroup per tile.
+// Measured and dropped in round 3 (profiles/r03_attn_balance_ab.txt): serving the remainder round of a big launch (config 2 at
+// batch 8: 768 tiles on 512 slots = 1.5 rounds) key-split as a SECOND launch of 256 x 2 parts -- 0.2514 ms per call against
+// 0.2403 ms: the first launch's workgroups do not finish together (the younger workgroup of each CU runs at 7400 cycles per
+// key tile against the older one's 5400), so the launch boundary idles every slot the early finishers free.
 struct WattnPlan {
-    int full;       // tiles served one workgroup each (first launch; 0: none)
-    int rem;        // tiles served key-split (second launch, or the only one; 0: none)
+    int full;       // tiles served one workgroup each (0: none)
+    int rem;        // tiles served key-split (0: none)
     int split;      // parts per tile of the key-split launch (1 when rem == 0)
+    int waves;      // waves per workgroup: 4 (128 queries) or 8 (256 queries, one workgroup per CU)
 };
 
-static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
+static WattnPlan wattn_plan(int n, int windows_x_streams, bool can_split) {
+    const int ntiles = (n + 31) / 32;
+    const int total = ((n + 127) / 128) * windows_x_streams;
     const int slots = 2 * wattn_num_cus();
-    if (!can_split) return {total, 0, 1};
-    if (total <= slots) {
+    static const int w8 = [] { const char* e = um_debug_env("UM_WATTN_W8"); return e ? atoi(e) : UM_WATTN_W8_DEFAULT; }();
+    // 256-query workgroups: only where they tile the window as well as 128-query ones do and the launch is more than a round
+    if (w8 && total > slots && ((n + 127) / 128) % 2 == 0) return {((n + 255) / 256) * windows_x_streams, 0, 1, 8};
+    if (can_split && total <= slots) {
         const int split = wattn_key_split(total, ntiles);
-        return split > 1 ? WattnPlan{0, total, split} : WattnPlan{total, 0, 1};
+        if (split > 1) return {0, total, split, 4};
     }
-    static const bool off = um_debug_env("UM_WATTN_NO_BALANCE") != nullptr;     // A/B switch (diagnostic builds)
-    const int rem = total % slots;
-    if (off || rem == 0) return {total, 0, 1};
-    int k = 1;
-    while (k < 4 && rem * (2 * k) <= slots && ntiles >= 4 * (2 * k)) k *= 2;
-    if (k == 1) return {total, 0, 1};
-    return {total - rem, rem, k};
+    return {total, 0, 1, 4};
 }
 
 static size_t wattn_ks_bytes(int tiles, int split) {
     const size_t slots = (size_t)tiles * (split - 1);
-    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));
+    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));      // 4-wave workgroups
 }
 
 extern "C" size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w) {
     if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w) return 0;
-    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
-    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
+    const WattnPlan p = wattn_plan(win_h * win_w, (h / win_h) * (w / win_w) * streams, true);
     return p.rem > 0 ? wattn_ks_bytes(p.rem, p.split) : 0;
 }
 
 // launch plan of um_window_attn_qproj_merge_fwd for a geometry: tiles served whole / tiles served key-split / parts per split tile
+// (a tile is 128 queries, or 256 where the plan uses 8-wave workgroups: then full_tiles counts those)
 extern "C" int um_window_attn_plan(int streams, int h, int w, int win_h, int win_w, int* full_tiles, int* split_tiles, int* parts) {
     if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w || !full_tiles || !split_tiles || !parts)
         return UM_ERR_BAD_ARG;
-    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
-    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
+    const WattnPlan p = wattn_plan(win_h * win_w, (h / win_h) * (w / win_w) * streams, true);
     *full_tiles = p.full;
     *split_tiles = p.rem;
     *parts = p.split;
@@ -1030,8 +1060,18 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     if (wm && wq) {
         // the layer kernel (query projection + attention + merge + LayerNorm): whole rounds one workgroup per tile, small
         // launches and the remainder round key-split (wattn_plan); without workspace everything runs one workgroup per tile
-        WattnPlan p = wattn_plan(a.total, (a.n + 31) / 32, ks_ws != nullptr);
-        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1};
+        WattnPlan p = wattn_plan(a.n, a.nwin * streams, ks_ws != nullptr);
+        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1, 4};
+        if (p.waves == 8) {
+            a.nqt = (a.n + 255) / 256;
+            a.total = a.nqt * a.nwin * streams;
+            um_census_hit(UM_V_WATTN_TILE);
+            if (mode == 0)
+                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, false, 8>), dim3(a.total), dim3(512), 0, stream, a);
+            else
+                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, false, 8>), dim3(a.total), dim3(512), 0, stream, a);
+            return (int)hipGetLastError();
+        }
         if (p.full > 0) {
             um_census_hit(UM_V_WATTN_TILE);
             if (mode == 0)
