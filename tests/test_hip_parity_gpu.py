@@ -968,6 +968,10 @@ def test_attention_merge_and_kv_rotate(ops, shifted, residual):
     (2, 40, 56, 20, 28, 10, 14, 1),     # config-1 geometry (560-token shifted windows, ragged last key tile): 4 parts of 4.5 tiles
     (2, 32, 48, 16, 24, 8, 12, 1),      # 384-token shifted windows, 12 key tiles: 2 parts
     (1, 64, 96, 32, 48, 16, 24, 0),     # batch-1 config-2 geometry: 48 query tiles, 2 parts
+    # big launches (more than one round of resident workgroups): the instantiation bench.py times
+    (16, 64, 96, 32, 48, 16, 24, 8),    # config 2 at batch 8, shifted, cross-attention rotation
+    (12, 40, 56, 20, 28, 0, 0, 0),      # 560-token windows (5 query tiles of 128: ragged last tile), 240 tiles ... small launch
+    (32, 60, 80, 30, 40, 15, 20, 16),   # config 5 at batch 16: 1200-token windows (ragged key tile), 1280 query tiles
 ])
 def test_query_projection_prologue_matches_q_planes(ops, geo):
     """um_window_attn_qproj_merge_fwd against um_window_attn_merge_fwd fed with q planes from um_linear_fwd, over window
