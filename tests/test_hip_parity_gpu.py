@@ -1298,3 +1298,31 @@ def test_rccl_allgather_at_world_size_one(tmp_path):
     gather, kind = make_gather(0, 1, dev)                                      # what bench.py / all_gather_predictions use
     assert 'um_allgather_preds' in kind and gather.ranks() == 1
     gather.close()
+
+
+def test_survey_named_entry_points(ops):
+    """SURVEY.md 8(b)'s literal names (um_swin_attn_fwd, um_attn1d_fwd, um_local_corr_softmax_1d, um_workspace_bytes_<op>) are
+    exported and do what the entry points they forward to do: bitwise the same outputs."""
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    st = torch.cuda.current_stream().cuda_stream
+    s_, h, w = 2, 16, 24
+    q, k, v = (rnd(990 + i, s_, h * w, C).to(DEV) for i in range(3))
+    for name, geom, call in (
+            ('swin', (8, 12, 4, 6), lambda o, ws: lib.um_swin_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), s_, h, w, C,
+                                                                        8, 12, 4, 6, 0, ws.data_ptr(), ws.numel(), st)),
+            ('attn1d', (1, 12, 0, 6), lambda o, ws: lib.um_attn1d_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), s_, h, w, C,
+                                                                       12, 6, 0, ws.data_ptr(), ws.numel(), st))):
+        nbytes = getattr(lib, f'um_workspace_bytes_{"swin_attn_fwd" if name == "swin" else "attn1d_fwd"}')(s_, h, w, C, 0)
+        assert nbytes == lib.um_window_attn_workspace_bytes(s_, h * w, C, 0) > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        out = torch.empty_like(q)
+        assert call(out, ws) == 0
+        assert torch.equal(out, ops.window_attention(q, k, v, h, w, *geom)), name
+    f0, f1 = rnd(995, 2, C, 12, 20), rnd(996, 2, C, 12, 20)
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    out = torch.empty(2, 1, 12, 20, device=DEV)
+    assert lib.um_local_corr_softmax_1d(t0.data_ptr(), t1.data_ptr(), out.data_ptr(), 2, 12, 20, C, 4, st) == 0
+    assert torch.equal(out, ops.local_corr_softmax(t0, t1, 12, 20, 4, one_d=True))
+    assert lib.um_workspace_bytes_global_corr_softmax_flow(2, 12, 20, C, 0) == lib.um_global_corr_workspace_bytes(2, 240, C, 0)
+    assert lib.um_workspace_bytes_local_corr_with_flow(2, 12, 20, C, 0) == 0 and lib.um_workspace_bytes_allgather_preds(2, 12, 20, C, 0) == 0
