@@ -115,8 +115,9 @@ def _cpu_task(cfg, which, kind, seed, idx, threads):
 
 
 class CpuLegs:
-    """Worker pool for the CPU legs.  ``submit`` queues samples (longest configs first), ``get`` waits for one."""
-    COST = {4: 80, 3: 52, 2: 5, 5: 3.3, 1: 2}
+    """Worker pool for the CPU legs.  ``submit`` queues samples in the given order, ``get`` waits for one.  Costs on the GPU
+    box's host with 12 x 16 threads busy (memory-bound fp64): ~11 s per config-2 sample, several minutes per config-3 / -4 sample;
+    ``--stage cpu`` fills the cache anywhere (e.g. in the build container) so that a GPU call only pays for the GPU legs."""
 
     def __init__(self, workers=None, threads=None, cache=None):
         self.cache = cache                       # directory: CPU legs survive across runs of the tool (A/B of library builds)
@@ -130,7 +131,7 @@ class CpuLegs:
         import multiprocessing as mp
         if self.pool is None:
             self.pool = mp.get_context('spawn').Pool(self.workers)
-        for key in sorted(set(keys), key=lambda k: -self.COST.get(k[0], 1)):
+        for key in keys:                          # in the caller's order: rows of the table stream out as their samples finish
             if key not in self.pending and key not in self.done:
                 self.pending[key] = self.pool.apply_async(cpu_task, (tuple(key) + (self.threads, self.cache),))
 
@@ -233,6 +234,7 @@ def main():
     ap.add_argument('--threads', type=int, default=None)
     ap.add_argument('--out', default=None)
     ap.add_argument('--cache', default=None, help='directory for the CPU legs (reused by later runs, e.g. other library builds)')
+    ap.add_argument('--stage', default='gpu', choices=['gpu', 'cpu'], help="'cpu': only compute the CPU legs into --cache (no GPU needed)")
     a = ap.parse_args()
     cfgs = [int(c) for c in a.configs.split(',')]
     legs = CpuLegs(a.workers, a.threads, a.cache)
@@ -241,6 +243,15 @@ def main():
     nb = lambda cfg: RUNS[cfg][3] if a.batch == 'config' else 1
     legs.submit([(cfg, which, kind, seed, i) for cfg, which, kind, seed in cases for i in range(nb(cfg))])
     print(f'# {len(cases)} cases, CPU legs on {legs.workers} workers x {legs.threads} threads', flush=True)
+    if a.stage == 'cpu':
+        assert a.cache, '--stage cpu needs --cache'
+        todo = [(cfg, which, kind, seed, i) for cfg, which, kind, seed in cases for i in range(nb(cfg))]
+        for n_done, key in enumerate(todo):
+            legs.get(key)
+            legs.done.pop(key, None)               # the record is on disk; do not hold every truth in memory
+            print(f'{n_done + 1}/{len(todo)} {key}', flush=True)
+        legs.close()
+        return
     hdr = (f'{"config":30s} {"weights":11s} {"kind":5s} {"n":>3s} {"GPU-fp64 mean":>13s} {"max":>9s} {"port-fp64 mean":>14s} {"max":>9s} '
            f'{"ratio mean":>10s} {"p99":>6s} {"max":>6s}  gate')
     print(hdr, flush=True)

@@ -1,4 +1,7 @@
-"""Diagnostic: section-level cycle stamps of the attention kernel (needs a -DUM_TRACE build: UM_LIB=tools/abl/lib_trace.so)."""
+"""Diagnostic: section-level cycle stamps of the attention layer kernel (needs a -DUM_TRACE build:
+``python -m unimatch_amd.build --variant trace -DUM_TRACE [-DUM_WATTN_PIPE_DEFAULT=1]``, then ``UM_LIB=.../libtrace.so``).
+Config-2 geometry at batch 8 (16 streams, 64 x 96 map, 32 x 48 windows) through um_window_attn_qproj_merge_fwd; every 37th
+workgroup stamps s_memtime at the section boundaries of its first 24 key tiles."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,27 +9,33 @@ sys.path.insert(0, ROOT)
 from unimatch_amd import _abi
 from unimatch_amd.ops import HipOps
 ops = HipOps('exact'); lib = _abi.load()
-S, h, w, C = 16, 64, 96, 128
+names = sys.argv[1].split(',') if len(sys.argv) > 1 else ['s0', 's1', 's2', 's3', 's4', 's5']
+s_, h, w, c = 16, 64, 96, 128
 g = torch.Generator(device='cuda').manual_seed(0)
-q, k, v = (torch.randn(S, h * w, C, device='cuda', generator=g) * 2 for _ in range(3))
+norm = torch.nn.LayerNorm(c).cuda()
+wq, wk, wv, wm = (torch.randn(c, c, device='cuda', generator=g) * 0.09 for _ in range(4))
+m = s_ * h * w
+x = torch.randn(m, c, device='cuda', generator=g) * 1.5
+kv, _, n2 = ops.linear_planes(x, (wk, wv))
+fn = lambda: ops.window_attention_qproj_merge(x, wq, (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, 32, 48, 0, 0, s_ // 2, wm, norm, x)
 nwg = 768
 buf = torch.zeros((nwg // 37 + 1) * (24 * 8 + 8), dtype=torch.int64, device='cuda')
 raw = ctypes.CDLL(_abi.LIB_PATH)
 for _ in range(2):
-    ops.window_attention(q, k, v, h, w, 32, 48, 0, 0)
+    fn()
 torch.cuda.synchronize()
 raw.um_debug_set_trace(ctypes.c_void_p(buf.data_ptr()))
-ops.window_attention(q, k, v, h, w, 32, 48, 0, 0)
+fn()
 torch.cuda.synchronize()
 raw.um_debug_set_trace(ctypes.c_void_p(0))
 b = buf.cpu().view(-1, 24 * 8 + 8)
-names = ['bias+rescale', 'QK+dma+addr', 'bias-add', 'PV||softmax', 'dma-wait', 'barrier']
-t0 = b[:, 24 * 8].min().item()
+t0 = b[:, 24 * 8][b[:, 24 * 8] > 0].min().item()
 for i in range(b.shape[0]):
     st = b[i, :24 * 8].view(24, 8)
     if st[0, 0] == 0:
         continue
-    d = (st[:, 1:7] - st[:, 0:6]).double()          # per-section cycles per tile
+    ns = len(names)
+    d = (st[:, 1:ns + 1] - st[:, 0:ns]).double()          # per-section cycles per tile
     per_tile = (st[1:, 0] - st[:-1, 0]).double().mean().item()
-    print(f'wg {i*37:4d} start {b[i,192].item()-t0:8d} total {b[i,193].item()-b[i,192].item():8d} cyc  per-tile {per_tile:7.0f}  ' +
+    print(f'wg {i*37:4d} start {b[i,192].item()-t0:9d} total {b[i,193].item()-b[i,192].item():8d} cyc  per-tile {per_tile:7.0f}  ' +
           '  '.join(f'{n} {d[2:, j].mean().item():6.0f}' for j, n in enumerate(names)))

@@ -46,6 +46,9 @@ __device__ unsigned long long* g_um_trace = nullptr;
 #ifndef UM_WATTN_W8_DEFAULT
 #define UM_WATTN_W8_DEFAULT 0       // 1: big launches of the layer kernel use 256-query (8-wave) workgroups, see wattn_plan
 #endif
+#ifndef UM_WATTN_PIPE_DEFAULT
+#define UM_WATTN_PIPE_DEFAULT 0     // 1: big launches of the layer kernel use the software-pipelined one-wave-per-SIMD instantiation
+#endif
 
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
@@ -117,14 +120,58 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
 // per SIMD, but both read the SAME staged tiles: half the LDS-DMA requests per wave and tile (4 instead of 8; their issue is
 // 60 - 185 cycles each beside MFMAs, MI355X_MICROARCH.md) and a 4-slot ring with the DMA running THREE tiles ahead, so that the
 // per-tile wait for the wave's own pieces (2-slot ring: ~350 cycles of exposed memory latency under load) finds them landed.
-template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
+//
+// PIPE (WAVES = 4, ONE workgroup per CU = one wave per SIMD, 512 registers per lane): the main loop software-pipelined inside
+// the wave.  With two waves per SIMD each wave runs QK^T -> softmax -> PV strictly in turn and relies on its partner to keep the
+// matrix pipe busy during its ~1100-cycle softmax; measured, the pair overlaps only half of it (pipe busy 48 - 51 %).  Here the
+// QK^T MFMAs of tile t+1 and the softmax of tile t are ONE instruction stream: every MFMA is followed by its share of the exp /
+// hi|lo split / permlane stages (4.1 fillers per MFMA, under the ~5 a lone wave hides in an MFMA's 32-cycle shadow), pinned
+// there by scheduling fences; the chain alternates two accumulators (a filler between two MFMAs on the same accumulator costs
+// the forwarding path); the Q fragments live in the accumulator file (asm MFMAs with the B operand constrained to AGPRs), which
+// leaves the VGPR file to O^T, the double score accumulators and the fragments; the LDS-DMA of tile t+3 is issued in the gaps
+// of the PV MFMAs of tile t (4-slot ring, K read one tile ahead of V).
+template <class T> struct WattnMfmaA;
+template <> struct WattnMfmaA<Fp16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    }
+};
+template <> struct WattnMfmaA<Bf16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    }
+};
+
+// O^T += A . B with the accumulator pinned in the accumulator file (PIPE: hipcc otherwise homes O^T in VGPRs around the rare
+// rescale and copies all 64 registers AGPR -> VGPR -> AGPR in every tile)
+template <class T> struct WattnMfmaO;
+template <> struct WattnMfmaO<Fp16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+    }
+};
+template <> struct WattnMfmaO<Bf16> {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+    }
+};
+
+template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false, int WAVES = 4, bool PIPE = false>
+__global__ __launch_bounds__(64 * WAVES, PIPE ? 1 : 2) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2)))
+void window_attn_kernel(WattnArgs a) {
+    static_assert(!PIPE || (WAVES == 4 && MERGE && QPROJ && !KSPLIT), "PIPE is an instantiation of the layer kernel only");
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
     // table [4 query classes][TK].  NSLOT buffers: tiles t+1 .. t+DIST stream in by LDS-DMA while tile t is consumed.
     constexpr int THREADS = 64 * WAVES;
     constexpr int QT = 32 * WAVES;                 // queries per workgroup
-    constexpr int NSLOT = (WAVES == 8) ? 4 : 2;
+    constexpr int NSLOT = (WAVES == 8 || PIPE) ? 4 : 2;
     constexpr int DIST = NSLOT - 1;                // tiles the staging runs ahead
     constexpr int TK = 32;
     constexpr int PLANE = TK * 256;
@@ -292,12 +339,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) __attribute__((amdgpu_waves_per_eu(2
         }
         __syncthreads();        // every wave is done with Wq: the ring may take tile 0
     }
+    if constexpr (PIPE) {       // the Q^T fragments move to the accumulator file for good (every later use is an "a" operand)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[pl][ks]));
+    }
 
     f32x16 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) asm volatile("" : "+a"(o[dt]));
+    }
     float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
 
     // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
@@ -616,12 +673,217 @@ __global__ __launch_bounds__(64 * WAVES, 2) __attribute__((amdgpu_waves_per_eu(2
         __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
-    for (int t = t0; t < t1; t += NSLOT) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
-        if constexpr (NSLOT == 4) {
-            if (t + 2 < t1) tile(std::integral_constant<int, 2>{}, t + 2);
-            if (t + 3 < t1) tile(std::integral_constant<int, 3>{}, t + 3);
+    // ---- PIPE: the software-pipelined tile (see the comment above the kernel) -------------------------------------------------
+    // State between iterations: sa + sb = S^T(t) (raw q.k scores of tile t, from the MFMAs of iteration t-1 or the prologue).
+    f32x16 sa, sb;
+    constexpr int MFQ = (NS == 2) ? 3 : 1;
+    // the 24 (8) MFMAs of S^T for the K tile at `kbase`, fragment reads two k-steps ahead, `filler(slot)` after every MFMA
+    auto qk_chain = [&](const unsigned char* kbase, auto&& filler) {
+        i16x8 fh[3], fl[3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fh[ks] = *reinterpret_cast<const i16x8*>(kbase + koff[ks]);
+            if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(kbase + PLANE + koff[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int m3 = 0; m3 < MFQ; ++m3) {
+                const int slot = ks * MFQ + m3;
+                const i16x8 af = (NS == 2 && m3 == 0) ? fl[ks % 3] : fh[ks % 3];
+                const i16x8 bq = (NS == 2 && m3 == 1) ? qf[NS - 1][ks] : qf[0][ks];
+                if (slot == 0) WattnMfmaA<T>::init(sa, af, bq);
+                else if (slot == 1) WattnMfmaA<T>::init(sb, af, bq);
+                else if (slot & 1) WattnMfmaA<T>::acc(sb, af, bq);
+                else WattnMfmaA<T>::acc(sa, af, bq);
+                if (m3 == 0 && ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kbase + koff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kbase + PLANE + koff[ks + 2]);
+                }
+                filler(slot);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // score_max(): S^T = sa + sb (+ mask bias of the tile in `bslot`), row maximum over the lane's 16 scores -> sc, mxl
+    f32x16 sc;
+    float mxl = 0.f;
+    auto score_max = [&](const unsigned char* bslot, int tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = sa[r] + sb[r];
+        if (has_mask || (tt + 1) * TK > a.n) {
+            const float* bt = reinterpret_cast<const float*>(bslot + BIAS_OFF) + clsq * TK + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[4 * g + i] += bv[i];
+            }
+        }
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        mxl = mx;
+    };
+    auto tile_pipe = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const bool staging = t + DIST < t1;
+        unsigned char* nxt = lds + ((SLOT + DIST) % NSLOT) * BUF;      // the slot tile t - 1 was read from
+        const unsigned char* kb = lds + SLOT * BUF;
+        const unsigned char* kn = lds + ((SLOT + 1) % NSLOT) * BUF;    // K(t+1)
+        const unsigned char* vb = kb + NS * PLANE;
+        UM_STAMP(0);
+
+        // ---- [A] what is left un-hidden: the exchange of the row maximum with lane ^ 32 and the lazy exact rescale decision
+        // (sc = S^T(t) and the lane's maximum mxl were formed in the MFMA shadows of the previous iteration's [C])
+        {
+            float u, v2;
+            half_wave_pair(mxl, u, v2);
+            m = fmaxf(m, fmaxf(u, v2));
+        }
+        constexpr float LAG = (NS == 2) ? 1.f : 8.f;
+        const float Mn = -ceilf(m * c);
+        const bool move = Mn + LAG < M;
+        if (__any(move)) {                                            // rare: O^T leaves the accumulator file only in here
+            const float Mh = Mn - a.headroom;
+            const float resc = move ? fast_exp2(Mh - M) : 1.f;
+            M = move ? Mh : M;
+            l *= resc;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                asm volatile("" : "+a"(o[dt]));       // the AGPR -> VGPR copies are born HERE, inside the rare branch
+                f32x16 tmp = o[dt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmp[r] *= resc;
+                o[dt] = tmp;
+                asm volatile("" : "+a"(o[dt]));
+            }
+        }
+        const float mc = M + (float)PSHIFT;
+        UM_STAMP(1);
+
+        // ---- [B] S^T(t+1) on the matrix pipe | exp, running sum, hi|lo split and operand swaps of tile t in the MFMA shadows.
+        // 18 stages: E(j) = scale + exp of score pair j (4 VALU), L(j) = its running-sum adds and fp16 hi|lo words (5), W(ks) =
+        // the v_permlane32_swap pairs of k-step ks (4); the last tile of the walk runs the MFMAs on a stale slot (results unused).
+        i16x8 pf[NS][2];
+        unsigned wh[8], wl[8];
+        int done = 0;
+        auto stage = [&](int i) {           // i: compile-time after unrolling
+            // order: E0 E1 L0 E2 L1 E3 L2 L3 W0 | E4 E5 L4 E6 L5 E7 L6 L7 W1
+            const int hb = i / 9, k = i % 9, j0 = 4 * hb;
+            auto E = [&](int j) {
+                sc[2 * j] = fast_exp2(__builtin_fmaf(sc[2 * j], c, mc));
+                sc[2 * j + 1] = fast_exp2(__builtin_fmaf(sc[2 * j + 1], c, mc));
+            };
+            auto L = [&](int j) {
+                l += sc[2 * j];
+                l += sc[2 * j + 1];
+                wh[j] = T::pack2(sc[2 * j], sc[2 * j + 1]);
+                if (NS == 2) wl[j] = T::lo2(sc[2 * j], sc[2 * j + 1], wh[j], neg1);
+            };
+            switch (k) {
+            case 0: E(j0); break;
+            case 1: E(j0 + 1); break;
+            case 2: L(j0); break;
+            case 3: E(j0 + 2); break;
+            case 4: L(j0 + 1); break;
+            case 5: E(j0 + 3); break;
+            case 6: L(j0 + 2); break;
+            case 7: L(j0 + 3); break;
+            default: {
+                {
+                    const auto x = __builtin_amdgcn_permlane32_swap(wh[j0], wh[j0 + 2], false, false);
+                    const auto y = __builtin_amdgcn_permlane32_swap(wh[j0 + 1], wh[j0 + 3], false, false);
+                    const u32x4 f = {x[0], y[0], x[1], y[1]};
+                    pf[0][hb] = __builtin_bit_cast(i16x8, f);
+                }
+                if (NS == 2) {
+                    const auto x = __builtin_amdgcn_permlane32_swap(wl[j0], wl[j0 + 2], false, false);
+                    const auto y = __builtin_amdgcn_permlane32_swap(wl[j0 + 1], wl[j0 + 3], false, false);
+                    const u32x4 f = {x[0], y[0], x[1], y[1]};
+                    pf[NS - 1][hb] = __builtin_bit_cast(i16x8, f);
+                }
+                break;
+            }
+            }
+        };
+        constexpr int NSTAGE = 18, NMF = 8 * MFQ;
+        qk_chain(kn, [&](int slot) {
+            const int upto = (slot + 1) * NSTAGE / NMF;
+            for (; done < upto; ++done) stage(done);
+        });
+        for (; done < NSTAGE; ++done) stage(done);
+        UM_STAMP(2);
+
+        // ---- [C] O^T += V(t)^T . P^T: asm MFMAs on the AGPR-resident O^T, product index outer and d-tile inner (a dependent MFMA
+        // right behind its predecessor waits ~20 cycles for the accumulator: consecutive MFMAs write different tiles).  In the
+        // gaps: the V fragments of the next k-step, the staging arithmetic + LDS-DMA of tile t+3, and S^T(t+1) = sa + sb with
+        // its row maximum for the next iteration.
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            i16x8 vh[2][4], vl[2][4];
+            auto vread = [&](int ks, int dt) {
+                const unsigned char* va = vb + voff[dt] + ks * 16 * 256;
+                const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va));
+                const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 4 * 256));
+                vh[ks][dt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (NS == 2) {
+                    const i16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + PLANE));
+                    const i16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + PLANE + 4 * 256));
+                    vl[ks][dt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vread(0, dt);
+            constexpr int MFP = (NS == 2) ? 3 : 1;
+            int slot = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mm = 0; mm < MFP; ++mm) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const i16x8 av = (NS == 2 && mm == 0) ? vl[ks][dt] : vh[ks][dt];
+                        const i16x8 bp = (NS == 2 && mm == 1) ? pf[NS - 1][ks] : pf[0][ks];
+                        WattnMfmaO<T>::acc(o[dt], av, bp);
+                        // fillers of this MFMA
+                        if (ks == 0 && mm == 0) vread(1, dt);                                   // slots 0 .. 3: next k-step's V
+                        if (slot == 4 && staging) stage_prepare(t + DIST, nxt);                 // staging arithmetic of tile t+3
+                        if (slot >= 6 && slot < 6 + 2 * NPAIR && ((slot - 6) & 1) == 0 && staging) stage_pair((slot - 6) / 2, nxt);
+                        if (slot == 8 * MFP - 6) score_max(kn, t + 1);                          // S^T(t+1): complete since [B]
+                        ++slot;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        UM_STAMP(3);
+        // K(t+2) and V(t+1) are needed next: only the pieces of tile t+3 (issued above) may still be in flight
+        if (staging) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPAIR * NJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UM_STAMP(4);
+        __syncthreads();
+        UM_STAMP(5);
+    };
+    if constexpr (PIPE) {
+        // prologue of the pipeline: S^T(t0) with nothing to hide behind it
+        qk_chain(lds, [&](int) {});
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // asm MFMA -> VALU read distance (hipcc does not see the MFMAs)
+        score_max(lds, t0);
+        for (int t = t0; t < t1; t += 4) {
+            tile_pipe(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < t1) tile_pipe(std::integral_constant<int, 1>{}, t + 1);
+            if (t + 2 < t1) tile_pipe(std::integral_constant<int, 2>{}, t + 2);
+            if (t + 3 < t1) tile_pipe(std::integral_constant<int, 3>{}, t + 3);
+        }
+    } else {
+        for (int t = t0; t < t1; t += NSLOT) {
+            tile(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
+            if constexpr (NSLOT == 4) {
+                if (t + 2 < t1) tile(std::integral_constant<int, 2>{}, t + 2);
+                if (t + 3 < t1) tile(std::integral_constant<int, 3>{}, t + 3);
+            }
         }
     }
     if constexpr (KSPLIT) {
@@ -855,6 +1117,7 @@ struct WattnPlan {
     int rem;        // tiles served key-split (0: none)
     int split;      // parts per tile of the key-split launch (1 when rem == 0)
     int waves;      // waves per workgroup: 4 (128 queries) or 8 (256 queries, one workgroup per CU)
+    int pipe;       // 1: the software-pipelined instantiation (128 queries, one workgroup per CU = one wave per SIMD)
 };
 
 static WattnPlan wattn_plan(int n, int windows_x_streams, bool can_split) {
@@ -863,12 +1126,15 @@ static WattnPlan wattn_plan(int n, int windows_x_streams, bool can_split) {
     const int slots = 2 * wattn_num_cus();
     static const int w8 = [] { const char* e = um_debug_env("UM_WATTN_W8"); return e ? atoi(e) : UM_WATTN_W8_DEFAULT; }();
     // 256-query workgroups: only where they tile the window as well as 128-query ones do and the launch is more than a round
-    if (w8 && total > slots && ((n + 127) / 128) % 2 == 0) return {((n + 255) / 256) * windows_x_streams, 0, 1, 8};
+    static const int pipe = [] { const char* e = um_debug_env("UM_WATTN_PIPE"); return e ? atoi(e) : UM_WATTN_PIPE_DEFAULT; }();
+    // software-pipelined workgroups (one per CU): launches of at least one full round of them, windows of at least 8 key tiles
+    if (pipe && 2 * total >= slots && ntiles >= 8) return {total, 0, 1, 4, 1};
+    if (w8 && total > slots && ((n + 127) / 128) % 2 == 0) return {((n + 255) / 256) * windows_x_streams, 0, 1, 8, 0};
     if (can_split && total <= slots) {
         const int split = wattn_key_split(total, ntiles);
-        if (split > 1) return {0, total, split, 4};
+        if (split > 1) return {0, total, split, 4, 0};
     }
-    return {total, 0, 1, 4};
+    return {total, 0, 1, 4, 0};
 }
 
 static size_t wattn_ks_bytes(int tiles, int split) {
@@ -1061,7 +1327,15 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
         // the layer kernel (query projection + attention + merge + LayerNorm): whole rounds one workgroup per tile, small
         // launches and the remainder round key-split (wattn_plan); without workspace everything runs one workgroup per tile
         WattnPlan p = wattn_plan(a.n, a.nwin * streams, ks_ws != nullptr);
-        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1, 4};
+        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1, 4, 0};
+        if (p.pipe) {
+            um_census_hit(UM_V_WATTN_TILE);
+            if (mode == 0)
+                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, false, 4, true>), dim3(a.total), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, false, 4, true>), dim3(a.total), dim3(256), 0, stream, a);
+            return (int)hipGetLastError();
+        }
         if (p.waves == 8) {
             a.nqt = (a.n + 255) / 256;
             a.total = a.nqt * a.nwin * streams;
