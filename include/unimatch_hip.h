@@ -148,9 +148,8 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
  * (exact).  The byte count is 0 for launches that are not split. */
 size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w);
 /* The launch plan of um_window_attn_qproj_merge_fwd for a geometry, a pure function of the arguments and the current device's CU
- * count: `full_tiles` query tiles are served one workgroup each, `split_tiles` tiles by `parts` workgroups each on a share of the
- * window's key tiles (small launches only: every workgroup resident at once).  A tile is 128 queries (256 where the build serves
- * big launches with 8-wave workgroups). */
+ * count: `full_tiles` 128-query tiles are served one workgroup each, `split_tiles` tiles by `parts` workgroups each on a share of
+ * the window's key tiles (small launches only: every workgroup resident at once). */
 int um_window_attn_plan(int streams, int h, int w, int win_h, int win_w, int* full_tiles, int* split_tiles, int* parts);
 int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_planes, const void* k_planes, const void* v_planes,
                                    const void* wm_planes, const float* gamma, const float* beta, const float* residual, float eps,

@@ -43,12 +43,6 @@ __device__ unsigned long long* g_um_trace = nullptr;
 #ifndef UM_WATTN_P1
 #define UM_WATTN_P1 0
 #endif
-#ifndef UM_WATTN_W8_DEFAULT
-#define UM_WATTN_W8_DEFAULT 0       // 1: big launches of the layer kernel use 256-query (8-wave) workgroups, see wattn_plan
-#endif
-#ifndef UM_WATTN_PIPE_DEFAULT
-#define UM_WATTN_PIPE_DEFAULT 0     // 1: big launches of the layer kernel use the software-pipelined one-wave-per-SIMD instantiation
-#endif
 
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
@@ -115,64 +109,11 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const unsigned char*
                  : "memory");
 }
 
-// WAVES = 4: workgroup = 128 queries, two workgroups per CU, 2-slot K/V ring (tile t+1 streams in while tile t is consumed).
-// WAVES = 8 (big launches of the layer kernel, see wattn_plan): workgroup = 256 queries, ONE workgroup per CU -- the same two waves
-// per SIMD, but both read the SAME staged tiles: half the LDS-DMA requests per wave and tile (4 instead of 8; their issue is
-// 60 - 185 cycles each beside MFMAs, MI355X_MICROARCH.md) and a 4-slot ring with the DMA running THREE tiles ahead, so that the
-// per-tile wait for the wave's own pieces (2-slot ring: ~350 cycles of exposed memory latency under load) finds them landed.
-//
-// PIPE (WAVES = 4, ONE workgroup per CU = one wave per SIMD, 512 registers per lane): the main loop software-pipelined inside
-// the wave.  With two waves per SIMD each wave runs QK^T -> softmax -> PV strictly in turn and relies on its partner to keep the
-// matrix pipe busy during its ~1100-cycle softmax; measured, the pair overlaps only half of it (pipe busy 48 - 51 %).  Here the
-// QK^T MFMAs of tile t+1 and the softmax of tile t are ONE instruction stream: every MFMA is followed by its share of the exp /
-// hi|lo split / permlane stages (4.1 fillers per MFMA, under the ~5 a lone wave hides in an MFMA's 32-cycle shadow), pinned
-// there by scheduling fences; the chain alternates two accumulators (a filler between two MFMAs on the same accumulator costs
-// the forwarding path); the Q fragments live in the accumulator file (asm MFMAs with the B operand constrained to AGPRs), which
-// leaves the VGPR file to O^T, the double score accumulators and the fragments; the LDS-DMA of tile t+3 is issued in the gaps
-// of the PV MFMAs of tile t (4-slot ring, K read one tile ahead of V).
-template <class T> struct WattnMfmaA;
-template <> struct WattnMfmaA<Fp16> {
-    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-    }
-    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-    }
-};
-template <> struct WattnMfmaA<Bf16> {
-    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-    }
-    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-    }
-};
-
-// O^T += A . B with the accumulator pinned in the accumulator file (PIPE: hipcc otherwise homes O^T in VGPRs around the rare
-// rescale and copies all 64 registers AGPR -> VGPR -> AGPR in every tile)
-template <class T> struct WattnMfmaO;
-template <> struct WattnMfmaO<Fp16> {
-    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-    }
-};
-template <> struct WattnMfmaO<Bf16> {
-    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-    }
-};
-
-template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false, int WAVES = 4, bool PIPE = false>
-__global__ __launch_bounds__(64 * WAVES, PIPE ? 1 : 2) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2)))
-void window_attn_kernel(WattnArgs a) {
-    static_assert(!PIPE || (WAVES == 4 && MERGE && QPROJ && !KSPLIT), "PIPE is an instantiation of the layer kernel only");
+template <class T, int NS, bool MERGE, bool QPROJ = false, bool KSPLIT = false>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn_kernel(WattnArgs a) {
     // One LDS buffer = one tile of TK window tokens: K planes, V planes (linear 256-byte rows, 16-byte chunks
     // XOR-swizzled by the SOURCE address because global_load_lds writes lane-linear), and the additive bias
-    // table [4 query classes][TK].  NSLOT buffers: tiles t+1 .. t+DIST stream in by LDS-DMA while tile t is consumed.
-    constexpr int THREADS = 64 * WAVES;
-    constexpr int QT = 32 * WAVES;                 // queries per workgroup
-    constexpr int NSLOT = (WAVES == 8 || PIPE) ? 4 : 2;
-    constexpr int DIST = NSLOT - 1;                // tiles the staging runs ahead
+    // table [4 query classes][TK].  Two buffers: tile t+1 streams in by LDS-DMA while tile t is consumed.
     constexpr int TK = 32;
     constexpr int PLANE = TK * 256;
     constexpr int BIAS_OFF = 2 * NS * PLANE;
@@ -181,7 +122,7 @@ void window_attn_kernel(WattnArgs a) {
     // + window-local token -> (global token << 2 | mask class), tabulated once per workgroup when the window has at most
     // TAB_BYTES / 4 tokens (rounded up to tiles): a tile's staging arithmetic is then two LDS reads instead of ~40 VALU
     constexpr int TAB_BYTES = 8192;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * BUF + TAB_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + TAB_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,12 +152,12 @@ void window_attn_kernel(WattnArgs a) {
     if constexpr (QPROJ) {       // Wq -> the idle K/V ring, in flight while the token table is being built
         const int row4 = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 32 / WAVES; ++i) {
-            const int row = 4 * ((32 / WAVES) * wave + i) + row4;
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (8 * wave + i) + row4;
             const int cw = pc ^ (row & 15);
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * ((32 / WAVES) * wave + i)) * 256);
+                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
         }
     }
     const int ntiles = (a.n + TK - 1) / TK;
@@ -229,10 +170,10 @@ void window_attn_kernel(WattnArgs a) {
 #endif
 
     const bool use_tab = ntiles * TK * 4 <= TAB_BYTES;                  // uniform
-    const unsigned* tab = reinterpret_cast<const unsigned*>(lds + NSLOT * BUF);
+    const unsigned* tab = reinterpret_cast<const unsigned*>(lds + 2 * BUF);
     if (use_tab) {
         const int ty0 = wy * a.win_h, tx0 = wx * a.win_w;
-        for (int tl = tid; tl < ntiles * TK; tl += THREADS) {
+        for (int tl = tid; tl < ntiles * TK; tl += 256) {
             int ly = tl / a.win_w;
             const int lx = tl - ly * a.win_w;
             ly = min(ly, a.win_h - 1);                                  // past the window's last token: any valid row (masked)
@@ -241,13 +182,13 @@ void window_attn_kernel(WattnArgs a) {
             oy = oy >= a.h ? oy - a.h : oy;
             ox = ox >= a.w ? ox - a.w : ox;
             const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
-            reinterpret_cast<unsigned*>(lds + NSLOT * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
+            reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
         }
         if (!QPROJ) __syncthreads();                                    // QPROJ: the prologue's barriers below cover it
     }
 
     // ---- this lane's query -----------------------------------------------------------------------
-    const int tq = qt * QT + wave * 32 + (lane & 31);
+    const int tq = qt * 128 + wave * 32 + (lane & 31);
     int clsq;
     const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
     // per-lane LDS read offsets of an A-operand row tile (K tile, Wm / Wq rows): loop invariant
@@ -339,26 +280,16 @@ void window_attn_kernel(WattnArgs a) {
         }
         __syncthreads();        // every wave is done with Wq: the ring may take tile 0
     }
-    if constexpr (PIPE) {       // the Q^T fragments move to the accumulator file for good (every later use is an "a" operand)
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[pl][ks]));
-    }
 
     f32x16 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    if constexpr (PIPE) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) asm volatile("" : "+a"(o[dt]));
-    }
     float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
 
     // ---- LDS-DMA staging.  One wave instruction moves 64 lanes x 16 B = 4 token rows; wave w owns rows
-    // RPW w .. RPW w + RPW - 1 of the tile (RPW = 32 / WAVES: NJ = 2 instructions per plane with 4 waves, 1 with 8).  LDS chunk position cp of row r holds source chunk
+    // 8w..8w+7 of the tile (2 instructions per plane).  LDS chunk position cp of row r holds source chunk
     // cp ^ swz(r): swzK = r & 15 (A-fragment ds_read_b128 conflict free), swzV = (r & 3) << 2 (the 4 rows of a
     // ds_read_b64_tr_b16 group land in 4 different bank quarters).
     // The kernel is instruction-issue bound (rocprof + ablations, profiles/), so the per-tile addressing is kept
@@ -366,12 +297,11 @@ void window_attn_kernel(WattnArgs a) {
     // TK tokens per tile with one add / compare / select each.
     const int adv_y = TK / a.win_w, adv_x = TK - adv_y * a.win_w;      // TK tokens = adv_y rows + adv_x columns
     const int y0 = wy * a.win_h, x0 = wx * a.win_w;
-    constexpr int RPW = TK / WAVES, NJ = RPW / 4;
-    int sly[NJ], slx[NJ];                                                // staged rows (j = 0 .. NJ-1)
-    long ssrc_k[NJ], ssrc_v[NJ];                                         // lane-constant part of the source offsets
+    int sly[2], slx[2];                                                  // staged rows (j = 0, 1)
+    long ssrc_k[2], ssrc_v[2];                                           // lane-constant part of the source offsets
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int row = t0 * TK + RPW * wave + 4 * j + ((lane >> 4) & 3);   // TK is a multiple of 16: row & 15 is tile-local
+    for (int j = 0; j < 2; ++j) {
+        const int row = t0 * TK + 8 * wave + 4 * j + ((lane >> 4) & 3);     // TK is a multiple of 16: row & 15 is tile-local
         sly[j] = row / a.win_w;
         slx[j] = row - sly[j] * a.win_w;
         const int cp = lane & 15;
@@ -405,15 +335,15 @@ void window_attn_kernel(WattnArgs a) {
     // instructions per wave queues up in the CU's single address unit (measured: ~1100 of ~5400 cycles per
     // tile); issued one per k-step of the QK^T loop instead, each piece hides under three MFMAs.
     constexpr int NPIECE = 4 * NS;
-    const unsigned short* spk[NJ];
-    const unsigned short* spv[NJ];
+    const unsigned short* spk[2];
+    const unsigned short* spv[2];
     auto stage_prepare = [&](int t, unsigned char* base) {
         // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
         const bool need = has_mask || (t + 1) * TK > a.n;
         if (use_tab) {
-            const unsigned* tp = tab + t * TK + RPW * wave + ((lane >> 4) & 3);
+            const unsigned* tp = tab + t * TK + 8 * wave + ((lane >> 4) & 3);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const long goff = (kvbase + (long)(tp[4 * j] >> 2)) * a.ldkv;
                 spk[j] = a.kp + goff + ssrc_k[j];
                 spv[j] = a.vp + goff + ssrc_v[j];
@@ -427,7 +357,7 @@ void window_attn_kernel(WattnArgs a) {
             return;
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < 2; ++j) {
             int cls;
             const int tok = token_at(sly[j], slx[j], cls);
             advance(sly[j], slx[j]);
@@ -452,18 +382,13 @@ void window_attn_kernel(WattnArgs a) {
     auto stage_pair = [&](int ip, unsigned char* base) {        // ip = 0 .. NPAIR-1, compile-time after unrolling
         const int pl = ip >> 1, isv = ip & 1;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(
-            base + (RPW * wave) * 256 + (isv * NS + pl) * PLANE));
+            base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
+        const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
         unsigned keep;
-        if constexpr (NJ == 2) {
-            const unsigned short* s1 = (isv ? spv[NJ - 1] : spk[NJ - 1]) + pl * a.kv_plane_stride - 512;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
-        } else {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(s0), "s"(dst) : "memory");
-        }
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
     };
 
     const int li = lane & 15, lg = (lane >> 4) & 1;
@@ -476,15 +401,9 @@ void window_attn_kernel(WattnArgs a) {
             voff[dt] = rowb * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
     }
 
-    // prologue: tiles t0 .. t0 + DIST - 1 go into slots 0 .. DIST - 1 (tile t0 + d of the workgroup's walk lives in slot d % NSLOT)
+    stage_prepare(t0, lds);
 #pragma unroll
-    for (int d = 0; d < DIST; ++d) {
-        if (t0 + d < t1) {
-            stage_prepare(t0 + d, lds + d * BUF);
-#pragma unroll
-            for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds + d * BUF);
-        }
-    }
+    for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -492,9 +411,9 @@ void window_attn_kernel(WattnArgs a) {
     auto tile = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         UM_STAMP(0);
-        const bool staging = t + DIST < t1;
-        unsigned char* nxt = lds + ((SLOT + DIST) % NSLOT) * BUF;      // the slot tile t - 1 was read from
-        if (staging) stage_prepare(t + DIST, nxt);
+        const bool staging = t + 1 < t1;
+        unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
+        if (staging) stage_prepare(t + 1, nxt);
         const unsigned char* kb = lds + SLOT * BUF;
         const unsigned char* vb = kb + NS * PLANE;
 
@@ -664,227 +583,14 @@ void window_attn_kernel(WattnArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         UM_STAMP(4);
-        // this wave's share of tile t+1 has landed in LDS: with the DMA DIST tiles ahead only the pieces of tiles t+2 .. t+DIST
-        // (NPAIR * NJ each) may still be in flight -- they were issued a whole tile walk ago, the wait finds them done; the last
-        // DIST tiles of the walk issue nothing new and wait for everything
-        if (DIST > 1 && staging) asm volatile("s_waitcnt vmcnt(%0)" : : "n"((DIST - 1) * NPAIR * NJ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed in LDS
         UM_STAMP(5);
         __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
-    // ---- PIPE: the software-pipelined tile (see the comment above the kernel) -------------------------------------------------
-    // State between iterations: sa + sb = S^T(t) (raw q.k scores of tile t, from the MFMAs of iteration t-1 or the prologue).
-    f32x16 sa, sb;
-    constexpr int MFQ = (NS == 2) ? 3 : 1;
-    // the 24 (8) MFMAs of S^T for the K tile at `kbase`, fragment reads two k-steps ahead, `filler(slot)` after every MFMA
-    auto qk_chain = [&](const unsigned char* kbase, auto&& filler) {
-        i16x8 fh[3], fl[3];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            fh[ks] = *reinterpret_cast<const i16x8*>(kbase + koff[ks]);
-            if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(kbase + PLANE + koff[ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-            for (int m3 = 0; m3 < MFQ; ++m3) {
-                const int slot = ks * MFQ + m3;
-                const i16x8 af = (NS == 2 && m3 == 0) ? fl[ks % 3] : fh[ks % 3];
-                const i16x8 bq = (NS == 2 && m3 == 1) ? qf[NS - 1][ks] : qf[0][ks];
-                if (slot == 0) WattnMfmaA<T>::init(sa, af, bq);
-                else if (slot == 1) WattnMfmaA<T>::init(sb, af, bq);
-                else if (slot & 1) WattnMfmaA<T>::acc(sb, af, bq);
-                else WattnMfmaA<T>::acc(sa, af, bq);
-                if (m3 == 0 && ks + 2 < 8) {
-                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kbase + koff[ks + 2]);
-                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kbase + PLANE + koff[ks + 2]);
-                }
-                filler(slot);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    // score_max(): S^T = sa + sb (+ mask bias of the tile in `bslot`), row maximum over the lane's 16 scores -> sc, mxl
-    f32x16 sc;
-    float mxl = 0.f;
-    auto score_max = [&](const unsigned char* bslot, int tt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = sa[r] + sb[r];
-        if (has_mask || (tt + 1) * TK > a.n) {
-            const float* bt = reinterpret_cast<const float*>(bslot + BIAS_OFF) + clsq * TK + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sc[4 * g + i] += bv[i];
-            }
-        }
-        float mx = sc[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-        mxl = mx;
-    };
-    auto tile_pipe = [&](auto slot_c, int t) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        const bool staging = t + DIST < t1;
-        unsigned char* nxt = lds + ((SLOT + DIST) % NSLOT) * BUF;      // the slot tile t - 1 was read from
-        const unsigned char* kb = lds + SLOT * BUF;
-        const unsigned char* kn = lds + ((SLOT + 1) % NSLOT) * BUF;    // K(t+1)
-        const unsigned char* vb = kb + NS * PLANE;
-        UM_STAMP(0);
-
-        // ---- [A] what is left un-hidden: the exchange of the row maximum with lane ^ 32 and the lazy exact rescale decision
-        // (sc = S^T(t) and the lane's maximum mxl were formed in the MFMA shadows of the previous iteration's [C])
-        {
-            float u, v2;
-            half_wave_pair(mxl, u, v2);
-            m = fmaxf(m, fmaxf(u, v2));
-        }
-        constexpr float LAG = (NS == 2) ? 1.f : 8.f;
-        const float Mn = -ceilf(m * c);
-        const bool move = Mn + LAG < M;
-        if (__any(move)) {                                            // rare: O^T leaves the accumulator file only in here
-            const float Mh = Mn - a.headroom;
-            const float resc = move ? fast_exp2(Mh - M) : 1.f;
-            M = move ? Mh : M;
-            l *= resc;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                asm volatile("" : "+a"(o[dt]));       // the AGPR -> VGPR copies are born HERE, inside the rare branch
-                f32x16 tmp = o[dt];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmp[r] *= resc;
-                o[dt] = tmp;
-                asm volatile("" : "+a"(o[dt]));
-            }
-        }
-        const float mc = M + (float)PSHIFT;
-        UM_STAMP(1);
-
-        // ---- [B] S^T(t+1) on the matrix pipe | exp, running sum, hi|lo split and operand swaps of tile t in the MFMA shadows.
-        // 18 stages: E(j) = scale + exp of score pair j (4 VALU), L(j) = its running-sum adds and fp16 hi|lo words (5), W(ks) =
-        // the v_permlane32_swap pairs of k-step ks (4); the last tile of the walk runs the MFMAs on a stale slot (results unused).
-        i16x8 pf[NS][2];
-        unsigned wh[8], wl[8];
-        int done = 0;
-        auto stage = [&](int i) {           // i: compile-time after unrolling
-            // order: E0 E1 L0 E2 L1 E3 L2 L3 W0 | E4 E5 L4 E6 L5 E7 L6 L7 W1
-            const int hb = i / 9, k = i % 9, j0 = 4 * hb;
-            auto E = [&](int j) {
-                sc[2 * j] = fast_exp2(__builtin_fmaf(sc[2 * j], c, mc));
-                sc[2 * j + 1] = fast_exp2(__builtin_fmaf(sc[2 * j + 1], c, mc));
-            };
-            auto L = [&](int j) {
-                l += sc[2 * j];
-                l += sc[2 * j + 1];
-                wh[j] = T::pack2(sc[2 * j], sc[2 * j + 1]);
-                if (NS == 2) wl[j] = T::lo2(sc[2 * j], sc[2 * j + 1], wh[j], neg1);
-            };
-            switch (k) {
-            case 0: E(j0); break;
-            case 1: E(j0 + 1); break;
-            case 2: L(j0); break;
-            case 3: E(j0 + 2); break;
-            case 4: L(j0 + 1); break;
-            case 5: E(j0 + 3); break;
-            case 6: L(j0 + 2); break;
-            case 7: L(j0 + 3); break;
-            default: {
-                {
-                    const auto x = __builtin_amdgcn_permlane32_swap(wh[j0], wh[j0 + 2], false, false);
-                    const auto y = __builtin_amdgcn_permlane32_swap(wh[j0 + 1], wh[j0 + 3], false, false);
-                    const u32x4 f = {x[0], y[0], x[1], y[1]};
-                    pf[0][hb] = __builtin_bit_cast(i16x8, f);
-                }
-                if (NS == 2) {
-                    const auto x = __builtin_amdgcn_permlane32_swap(wl[j0], wl[j0 + 2], false, false);
-                    const auto y = __builtin_amdgcn_permlane32_swap(wl[j0 + 1], wl[j0 + 3], false, false);
-                    const u32x4 f = {x[0], y[0], x[1], y[1]};
-                    pf[NS - 1][hb] = __builtin_bit_cast(i16x8, f);
-                }
-                break;
-            }
-            }
-        };
-        constexpr int NSTAGE = 18, NMF = 8 * MFQ;
-        qk_chain(kn, [&](int slot) {
-            const int upto = (slot + 1) * NSTAGE / NMF;
-            for (; done < upto; ++done) stage(done);
-        });
-        for (; done < NSTAGE; ++done) stage(done);
-        UM_STAMP(2);
-
-        // ---- [C] O^T += V(t)^T . P^T: asm MFMAs on the AGPR-resident O^T, product index outer and d-tile inner (a dependent MFMA
-        // right behind its predecessor waits ~20 cycles for the accumulator: consecutive MFMAs write different tiles).  In the
-        // gaps: the V fragments of the next k-step, the staging arithmetic + LDS-DMA of tile t+3, and S^T(t+1) = sa + sb with
-        // its row maximum for the next iteration.
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            i16x8 vh[2][4], vl[2][4];
-            auto vread = [&](int ks, int dt) {
-                const unsigned char* va = vb + voff[dt] + ks * 16 * 256;
-                const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va));
-                const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 4 * 256));
-                vh[ks][dt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                if (NS == 2) {
-                    const i16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + PLANE));
-                    const i16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + PLANE + 4 * 256));
-                    vl[ks][dt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            };
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) vread(0, dt);
-            constexpr int MFP = (NS == 2) ? 3 : 1;
-            int slot = 0;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int mm = 0; mm < MFP; ++mm) {
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const i16x8 av = (NS == 2 && mm == 0) ? vl[ks][dt] : vh[ks][dt];
-                        const i16x8 bp = (NS == 2 && mm == 1) ? pf[NS - 1][ks] : pf[0][ks];
-                        WattnMfmaO<T>::acc(o[dt], av, bp);
-                        // fillers of this MFMA
-                        if (ks == 0 && mm == 0) vread(1, dt);                                   // slots 0 .. 3: next k-step's V
-                        if (slot == 4 && staging) stage_prepare(t + DIST, nxt);                 // staging arithmetic of tile t+3
-                        if (slot >= 6 && slot < 6 + 2 * NPAIR && ((slot - 6) & 1) == 0 && staging) stage_pair((slot - 6) / 2, nxt);
-                        if (slot == 8 * MFP - 6) score_max(kn, t + 1);                          // S^T(t+1): complete since [B]
-                        ++slot;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        }
-        UM_STAMP(3);
-        // K(t+2) and V(t+1) are needed next: only the pieces of tile t+3 (issued above) may still be in flight
-        if (staging) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPAIR * NJ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        UM_STAMP(4);
-        __syncthreads();
-        UM_STAMP(5);
-    };
-    if constexpr (PIPE) {
-        // prologue of the pipeline: S^T(t0) with nothing to hide behind it
-        qk_chain(lds, [&](int) {});
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // asm MFMA -> VALU read distance (hipcc does not see the MFMAs)
-        score_max(lds, t0);
-        for (int t = t0; t < t1; t += 4) {
-            tile_pipe(std::integral_constant<int, 0>{}, t);
-            if (t + 1 < t1) tile_pipe(std::integral_constant<int, 1>{}, t + 1);
-            if (t + 2 < t1) tile_pipe(std::integral_constant<int, 2>{}, t + 2);
-            if (t + 3 < t1) tile_pipe(std::integral_constant<int, 3>{}, t + 3);
-        }
-    } else {
-        for (int t = t0; t < t1; t += NSLOT) {
-            tile(std::integral_constant<int, 0>{}, t);
-            if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
-            if constexpr (NSLOT == 4) {
-                if (t + 2 < t1) tile(std::integral_constant<int, 2>{}, t + 2);
-                if (t + 3 < t1) tile(std::integral_constant<int, 3>{}, t + 3);
-            }
-        }
+    for (int t = t0; t < t1; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
     }
     if constexpr (KSPLIT) {
         // The slots are written and read ONLY by agent-scope accesses, which go through to memory themselves; a release /
@@ -892,8 +598,7 @@ void window_attn_kernel(WattnArgs a) {
         // completion of the stores before the flag is raised: vmcnt(0) + the barrier.
         // Slot layout: 17 vectors of 16 bytes per thread, [vector][thread] -- O^T (16 vectors: tile dt, register group g) then
         // (M, l, -, -).
-        constexpr int KS_SLOT = 17 * THREADS * 4;                    // floats per slot
-        constexpr int KS_VEC = THREADS * 4;                          // floats per vector row
+        constexpr int KS_SLOT = 17 * 256 * 4;                        // floats per slot
         if (part > 0) {
             const long slot = (long)wl * (nsplit - 1) + part - 1;
             float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
@@ -902,11 +607,11 @@ void window_attn_kernel(WattnArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    st_agent_16B(pr + (dt * 4 + g) * KS_VEC, v);
+                    st_agent_16B(pr + (dt * 4 + g) * 1024, v);
                 }
             {
                 const f32x4 v = {M, l, 0.f, 0.f};
-                st_agent_16B(pr + 16 * KS_VEC, v);
+                st_agent_16B(pr + 16 * 1024, v);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -921,7 +626,7 @@ void window_attn_kernel(WattnArgs a) {
             }
             __syncthreads();
             const float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
-            const f32x4 ml = ld_agent_16B(pr + 16 * KS_VEC);
+            const f32x4 ml = ld_agent_16B(pr + 16 * 1024);
             const float Mo = ml[0], lo = ml[1];
             const float Ms = fminf(M, Mo);                           // offsets are integers: the factors are powers of two
             const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
@@ -930,8 +635,8 @@ void window_attn_kernel(WattnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 w[4];
-                const float* q = pr + dt * 4 * KS_VEC;
-                ld_agent_16Bx4(q, q + KS_VEC, q + 2 * KS_VEC, q + 3 * KS_VEC, w[0], w[1], w[2], w[3]);
+                const float* q = pr + dt * 4 * 1024;
+                ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -974,12 +679,12 @@ void window_attn_kernel(WattnArgs a) {
     {
         const int row4 = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 32 / WAVES; ++i) {
-            const int row = 4 * ((32 / WAVES) * wave + i) + row4;  // wave w stages 128 / WAVES rows
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (8 * wave + i) + row4;             // wave w stages rows 32 w .. 32 w + 31
             const int c = pc ^ (row & 15);
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * c, lds + pl * 32768 + (4 * ((32 / WAVES) * wave + i)) * 256);
+                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * c, lds + pl * 32768 + (4 * (8 * wave + i)) * 256);
         }
     }
     i16x8 of[NS][8];
@@ -1108,52 +813,47 @@ static int wattn_key_split(int total, int ntiles) {
 //   * a small launch (every 128-query tile resident at once, two workgroups per CU): tiles key-split `split` ways while the
 //     launch stays resident (batch-1 latency);
 //   * a big launch: one workgroup per tile.
-// Measured and dropped in round 3 (profiles/r03_attn_balance_ab.txt): serving the remainder round of a big launch (config 2 at
-// batch 8: 768 tiles on 512 slots = 1.5 rounds) key-split as a SECOND launch of 256 x 2 parts -- 0.2514 ms per call against
-// 0.2403 ms: the first launch's workgroups do not finish together (the younger workgroup of each CU runs at 7400 cycles per
-// key tile against the older one's 5400), so the launch boundary idles every slot the early finishers free.
+// Round 3 measured four restructurings of the big launch on the GPU and dropped them all (profiles/r03_attention_experiments.txt;
+// the code is in git at 85b86af): the remainder round of 768 tiles on 512 slots key-split as a second launch (0.2514 against
+// 0.2403 ms: the first launch's workgroups do not finish together and the launch boundary idles the early finishers' slots);
+// 256-query / 8-wave workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time, worse quantisation);
+// a software-pipelined one-wave-per-SIMD instantiation with Q^T and O^T in AGPRs (0.293 against 0.260 ms); alternating
+// accumulators in QK^T / PV (0.262 against 0.241 ms).  What the section stamps of those builds showed: a lone wave issues one
+// 32x32x16 MFMA per ~45 cycles whatever sits between them (the power-limited rate, 1.72 PFLOP/s chip-wide on such operands),
+// and the two waves a SIMD holds keep the pipe at 85 % of THAT rate during the full round; the loss is the tail round.
 struct WattnPlan {
     int full;       // tiles served one workgroup each (0: none)
     int rem;        // tiles served key-split (0: none)
     int split;      // parts per tile of the key-split launch (1 when rem == 0)
-    int waves;      // waves per workgroup: 4 (128 queries) or 8 (256 queries, one workgroup per CU)
-    int pipe;       // 1: the software-pipelined instantiation (128 queries, one workgroup per CU = one wave per SIMD)
 };
 
-static WattnPlan wattn_plan(int n, int windows_x_streams, bool can_split) {
-    const int ntiles = (n + 31) / 32;
-    const int total = ((n + 127) / 128) * windows_x_streams;
+static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
     const int slots = 2 * wattn_num_cus();
-    static const int w8 = [] { const char* e = um_debug_env("UM_WATTN_W8"); return e ? atoi(e) : UM_WATTN_W8_DEFAULT; }();
-    // 256-query workgroups: only where they tile the window as well as 128-query ones do and the launch is more than a round
-    static const int pipe = [] { const char* e = um_debug_env("UM_WATTN_PIPE"); return e ? atoi(e) : UM_WATTN_PIPE_DEFAULT; }();
-    // software-pipelined workgroups (one per CU): launches of at least one full round of them, windows of at least 8 key tiles
-    if (pipe && 2 * total >= slots && ntiles >= 8) return {total, 0, 1, 4, 1};
-    if (w8 && total > slots && ((n + 127) / 128) % 2 == 0) return {((n + 255) / 256) * windows_x_streams, 0, 1, 8, 0};
     if (can_split && total <= slots) {
         const int split = wattn_key_split(total, ntiles);
-        if (split > 1) return {0, total, split, 4, 0};
+        if (split > 1) return {0, total, split};
     }
-    return {total, 0, 1, 4, 0};
+    return {total, 0, 1};
 }
 
 static size_t wattn_ks_bytes(int tiles, int split) {
     const size_t slots = (size_t)tiles * (split - 1);
-    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));      // 4-wave workgroups
+    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));
 }
 
 extern "C" size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w) {
     if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w) return 0;
-    const WattnPlan p = wattn_plan(win_h * win_w, (h / win_h) * (w / win_w) * streams, true);
+    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
+    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
     return p.rem > 0 ? wattn_ks_bytes(p.rem, p.split) : 0;
 }
 
 // launch plan of um_window_attn_qproj_merge_fwd for a geometry: tiles served whole / tiles served key-split / parts per split tile
-// (a tile is 128 queries, or 256 where the plan uses 8-wave workgroups: then full_tiles counts those)
 extern "C" int um_window_attn_plan(int streams, int h, int w, int win_h, int win_w, int* full_tiles, int* split_tiles, int* parts) {
     if (streams <= 0 || h <= 0 || w <= 0 || win_h <= 0 || win_w <= 0 || h % win_h || w % win_w || !full_tiles || !split_tiles || !parts)
         return UM_ERR_BAD_ARG;
-    const WattnPlan p = wattn_plan(win_h * win_w, (h / win_h) * (w / win_w) * streams, true);
+    const int n = win_h * win_w, total = ((n + 127) / 128) * (h / win_h) * (w / win_w) * streams;
+    const WattnPlan p = wattn_plan(total, (n + 31) / 32, true);
     *full_tiles = p.full;
     *split_tiles = p.rem;
     *parts = p.split;
@@ -1326,26 +1026,8 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     if (wm && wq) {
         // the layer kernel (query projection + attention + merge + LayerNorm): whole rounds one workgroup per tile, small
         // launches and the remainder round key-split (wattn_plan); without workspace everything runs one workgroup per tile
-        WattnPlan p = wattn_plan(a.n, a.nwin * streams, ks_ws != nullptr);
-        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1, 4, 0};
-        if (p.pipe) {
-            um_census_hit(UM_V_WATTN_TILE);
-            if (mode == 0)
-                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, false, 4, true>), dim3(a.total), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, false, 4, true>), dim3(a.total), dim3(256), 0, stream, a);
-            return (int)hipGetLastError();
-        }
-        if (p.waves == 8) {
-            a.nqt = (a.n + 255) / 256;
-            a.total = a.nqt * a.nwin * streams;
-            um_census_hit(UM_V_WATTN_TILE);
-            if (mode == 0)
-                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, false, 8>), dim3(a.total), dim3(512), 0, stream, a);
-            else
-                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, false, 8>), dim3(a.total), dim3(512), 0, stream, a);
-            return (int)hipGetLastError();
-        }
+        WattnPlan p = wattn_plan(a.total, (a.n + 31) / 32, ks_ws != nullptr);
+        if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1};
         if (p.full > 0) {
             um_census_hit(UM_V_WATTN_TILE);
             if (mode == 0)
