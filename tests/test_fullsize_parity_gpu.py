@@ -27,7 +27,10 @@ CASES = [(c, 'conditioned') for c in (1, 2, 3, 4, 5)] + [(c, 'ctor326') for c in
 
 @pytest.fixture(scope='module')
 def legs():
-    pool = pf.CpuLegs()
+    # CPU legs computed elsewhere (tools/parity_fullsize.py --stage cpu --cache gpurun_cache/parity, e.g. in the build container)
+    # are picked up when the directory travelled with the tree; otherwise everything is computed here
+    cache = os.path.join(ROOT, 'gpurun_cache', 'parity')
+    pool = pf.CpuLegs(cache=cache if os.path.isdir(cache) else None)
     # queue every sample of every case up front: the pool works through them while the GPU tests run
     pool.submit([(cfg, which, KIND, SEED, i) for cfg, which in CASES for i in range(pf.RUNS[cfg][3])])
     yield pool
