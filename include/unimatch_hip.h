@@ -146,6 +146,13 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
  * launch of few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking a whole window) gives every query tile
  * to 2 or 4 neighbouring workgroups, each on its share of the window's keys; the first merges the others' partial softmaxes
  * (exact).  The byte count is 0 for launches that are not split. */
+/* Assumptions of the split small launches (um_window_attn_qproj_merge_fwd with workspace, um_ffn_ws_fwd): the parts of a tile hand
+ * their partial results over through `workspace` while the kernel runs -- part 0 spins on a flag the other parts raise.  The host
+ * only splits while every workgroup of the launch fits the device at once (2 x CUs attention / 1 x CUs FFN workgroups, CU count of
+ * the current device), so the wait terminates provided nothing else occupies the device for the whole kernel AND withholds the
+ * remaining slots from this launch; partner workgroups are neighbours in dispatch order (same XCD), so in-order dispatch -- what
+ * the hardware does, not what HIP promises -- is enough even then.  The workspace must be zero before the first launch that uses it,
+ * is left with zero flags by every launch, and must not be shared by launches in flight on different streams. */
 size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w);
 /* The launch plan of um_window_attn_qproj_merge_fwd for a geometry, a pure function of the arguments and the current device's CU
  * count: `full_tiles` 128-query tiles are served one workgroup each, `split_tiles` tiles by `parts` workgroups each on a share of
@@ -402,6 +409,18 @@ int um_convex_upsample(const float* flow, const float* mask, float* up, int batc
  * SURVEY.md 8(f) rank 2. */
 int um_flow_warp(const float* feature_tokens, const float* flow, float* out_tokens, int batch, int h, int w, int channels,
                  void* stream);
+
+/* The per-scale loop's small glue ops (round 3: they were torch calls):
+ *   um_flow_upsample2x  out[B,V,2h,2w] = mult * bilinear_up2(flow[B,V,h,w]), align_corners = True -- unimatch/unimatch.py:162-163
+ *                       (F.interpolate(..., scale_factor=2, mode='bilinear', align_corners=True) * 2: pass mult = 2)
+ *   um_depth_cam_pack   cam[B or 2B][30] = Kinv | R | t | K (row major) from intrinsics [B,3,3] with rows 0-1 divided by stride_div
+ *                       (unimatch.py:147-150) and pose [B,4,4]; with bidir, entries B..2B-1 carry the inverse pose
+ *                       (matching.py:226-233).  Closed-form inverses: no torch.inverse (which synchronises the device)
+ *   um_rigid_flow       flow[B,2,h,w] induced by inv_depth [B,1,h,w] and cam [B][30]: unimatch/geometry.py:99-195 as called
+ *                       from the depth refinement (unimatch.py:295-305) */
+int um_flow_upsample2x(const float* flow, float* out, int batch, int channels, int h, int w, float mult, void* stream);
+int um_depth_cam_pack(const float* intrinsics, const float* pose, float* cam, int batch, float stride_div, int bidir, void* stream);
+int um_rigid_flow(const float* inv_depth, const float* cam, float* flow, int batch, int h, int w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder helper (outside the hot path of SURVEY.md section 8; added because the element-wise tail of the CNN encoder

@@ -1326,3 +1326,50 @@ def test_survey_named_entry_points(ops):
     assert torch.equal(out, ops.local_corr_softmax(t0, t1, 12, 20, 4, one_d=True))
     assert lib.um_workspace_bytes_global_corr_softmax_flow(2, 12, 20, C, 0) == lib.um_global_corr_workspace_bytes(2, 240, C, 0)
     assert lib.um_workspace_bytes_local_corr_with_flow(2, 12, 20, C, 0) == 0 and lib.um_workspace_bytes_allgather_preds(2, 12, 20, C, 0) == 0
+
+
+def test_per_scale_glue_kernels(ops):
+    """um_flow_upsample2x (unimatch.py:162-163), um_depth_cam_pack (K / stride, K^-1, pose and inverse pose in closed form instead of
+    torch.inverse) and um_rigid_flow (geometry.py:99-195) against fp64 evaluations of the reference expressions."""
+    flow = rnd(1100, 3, 2, 17, 23, scale=4.0)
+    want = 2 * torch.nn.functional.interpolate(flow.double(), scale_factor=2, mode='bilinear', align_corners=True)
+    got = ops.flow_upsample2x(flow.to(DEV), 2.0)
+    assert got.shape == want.shape and err(got, want)[0] < 2e-6 * max(1.0, want.abs().max().item())
+    b, h, w = 3, 30, 40
+    k, pose = synth_camera(b, 8 * h, 8 * w)
+    pose = pose.clone()
+    pose[1, :3, 3] *= -2.0                                                     # different poses per sample
+    pose[2, :3, :3] = pose[2, :3, :3] @ pose[0, :3, :3]
+    kd = k.double().clone()
+    kd[:, :2] /= 8.0
+    for bidir in (False, True):
+        cam = ops.depth_cam(k.to(DEV), pose.to(DEV), 8.0, bidir).cpu().double()
+        pd = torch.cat([pose.double(), torch.inverse(pose.double())], 0) if bidir else pose.double()
+        kk = kd.repeat(2, 1, 1) if bidir else kd
+        want = torch.cat([torch.inverse(kk).flatten(1), pd[:, :3, :3].flatten(1), pd[:, :3, 3], kk.flatten(1)], 1)
+        assert cam.shape == want.shape and (cam - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    inv_depth = (0.2 + rnd(1101, b, 1, h, w).abs()).clamp(0.1, 2.0)
+    cam = ops.depth_cam(k.to(DEV), pose.to(DEV), 8.0, False)
+    want = om.rigid_flow(1.0 / inv_depth.double().squeeze(1), kd, pose.double())
+    got = ops.rigid_flow(inv_depth.to(DEV), cam)
+    assert err(got, want)[0] < 5e-5 * max(1.0, want.abs().max().item())
+
+
+def test_hip_graph_replay_of_the_depth_path():
+    """With the camera packing on the device (no torch.inverse) the depth forward has no host synchronisation left: it is captured
+    into a HIP graph and replays bitwise equal to eager, also with the refinement step (gmdepth_s1_rr1)."""
+    from unimatch_amd.graph import GraphedUniMatch
+    for name in ('gmdepth_s1', 'gmdepth_s1_rr1'):
+        ck, fk = CONFIGS[name]
+        model = UniMatch(**ck).eval()
+        model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
+        model = model.to(DEV)
+        graphed = GraphedUniMatch(model)
+        for seed in (25, 26):
+            i0, i1 = synth_images(1, 96, 128, seed=seed, kind='shift', normalized=True)
+            k, pose = synth_camera(1, 96, 128)
+            kw = dict(fk, intrinsics=k.to(DEV), pose=pose.to(DEV))
+            want = model(i0.to(DEV), i1.to(DEV), **kw)['flow_preds'][0]
+            got = graphed(i0.to(DEV), i1.to(DEV), **kw)['flow_preds'][0]
+            assert torch.equal(got, want), (name, seed)
+        assert all(v is not False for v in graphed._graphs.values()), name

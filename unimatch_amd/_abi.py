@@ -63,6 +63,9 @@ SIGNATURES = {
     'um_nchw_to_nhwc': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_flow_warp': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_convex_upsample': (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),
+    'um_flow_upsample2x': (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
+    'um_depth_cam_pack': (_c_int, [_c_void_p] * 3 + [_c_int, ctypes.c_float, _c_int, _c_void_p]),
+    'um_rigid_flow': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'um_instance_norm_fwd': (_c_int, [_c_void_p] * 3 + [ctypes.c_long, _c_int, ctypes.c_float, _c_int, _c_void_p]),
     'um_global_corr_workspace_bytes': (_c_size_t, [_c_int] * 4),
     'um_global_corr_softmax_flow': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),

@@ -175,3 +175,135 @@ extern "C" int um_flow_warp(const float* feature_tokens, const float* flow, floa
                        out_tokens, batch, h, w, channels / 4);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------
+// The small glue ops of the per-scale loop that were still torch calls ("small torch ops on the path").
+//
+// flow_upsample2x: flow <- 2 * bilinear_up2(flow), align_corners = True (unimatch/unimatch.py:162-163): out[y2, x2] with
+// source position y2 * (h-1)/(2h-1), in ATen's operation order (h0 (w0 a + w1 b) + h1 (w0 c + w1 d)), times `mult`.
+__global__ __launch_bounds__(256) void flow_upsample2x_kernel(const float* __restrict__ flow, float* __restrict__ out, long planes, int h,
+                                                              int w, float rh, float rw, float mult) {
+    const int ho = 2 * h, wo = 2 * w;
+    const long total = planes * ho * wo;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x2 = (int)(i % wo);
+    const long t = i / wo;
+    const int y2 = (int)(t % ho);
+    const long pl = t / ho;
+    const float sy = rh * (float)y2, sx = rw * (float)x2;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* p = flow + pl * h * w + (long)y0 * w + x0;
+    const float v = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[yp * w] + lx1 * p[yp * w + xp]);
+    out[i] = v * mult;
+}
+
+
+extern "C" int um_flow_upsample2x(const float* flow, float* out, int batch, int channels, int h, int w, float mult, void* stream) {
+    if (!flow || !out || batch <= 0 || channels <= 0 || h <= 0 || w <= 0) {
+        um_set_error("um_flow_upsample2x: null pointer or non-positive size");
+        return -1;
+    }
+    const long planes = (long)batch * channels, total = planes * 4 * h * w;
+    const float rh = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f, rw = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    hipLaunchKernelGGL(flow_upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flow, out, planes,
+                       h, w, rh, rw, mult);
+    return (int)hipGetLastError();
+}
+
+// depth_cam_pack: the 30 floats per sample the depth kernels take -- Kinv[9] | R[9] | t[3] | K[9], row major -- from the caller's
+// intrinsics [B,3,3] (rows 0-1 divided by `stride_div`, unimatch/unimatch.py:147-150) and relative pose [B,4,4]; entries B .. 2B-1
+// (when `bidir`) hold the inverse pose (matching.py:226-233, unimatch.py:296-300).  Inverses in closed form (3x3 adjugate; a pose
+// is affine: [A t; 0 0 0 1]^-1 = [A^-1, -A^-1 t]) instead of torch.inverse, which synchronises the device and keeps the depth
+// path out of HIP graphs.
+__device__ __forceinline__ void inv3(const float* m, float* o) {
+    const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const float id = 1.0f / det;
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__global__ void depth_cam_pack_kernel(const float* __restrict__ intr, const float* __restrict__ pose, float* __restrict__ cam, int batch,
+                                      float stride_div, int bidir) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = bidir ? 2 * batch : batch;
+    if (i >= n) return;
+    const int b = i % batch;
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = j < 6 ? intr[b * 9 + j] / stride_div : intr[b * 9 + j];
+    float* c = cam + (long)i * 30;
+    inv3(k, c);
+    const float* p = pose + b * 16;
+    float r[9] = {p[0], p[1], p[2], p[4], p[5], p[6], p[8], p[9], p[10]}, t[3] = {p[3], p[7], p[11]};
+    if (i >= batch) {
+        float ri[9];
+        inv3(r, ri);
+        const float t0 = -(ri[0] * t[0] + ri[1] * t[1] + ri[2] * t[2]), t1 = -(ri[3] * t[0] + ri[4] * t[1] + ri[5] * t[2]),
+                    t2 = -(ri[6] * t[0] + ri[7] * t[1] + ri[8] * t[2]);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) r[j] = ri[j];
+        t[0] = t0;
+        t[1] = t1;
+        t[2] = t2;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c[9 + j] = r[j];
+    c[18] = t[0];
+    c[19] = t[1];
+    c[20] = t[2];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c[21 + j] = k[j];
+}
+
+extern "C" int um_depth_cam_pack(const float* intrinsics, const float* pose, float* cam, int batch, float stride_div, int bidir, void* stream) {
+    if (!intrinsics || !pose || !cam || batch <= 0 || !(stride_div > 0.f)) {
+        um_set_error("um_depth_cam_pack: null pointer, non-positive batch or stride divisor");
+        return -1;
+    }
+    const int n = bidir ? 2 * batch : batch;
+    hipLaunchKernelGGL(depth_cam_pack_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, intrinsics, pose, cam, batch, stride_div, bidir);
+    return (int)hipGetLastError();
+}
+
+// rigid_flow: the flow a depth map and a relative pose induce (unimatch/geometry.py:99-195, used by the depth refinement,
+// unimatch.py:295-305): X = R (Kinv [x y 1]^T) z + t, u = K X, flow = u_xy / max(u_z, 1e-3) - (x, y); z = 1 / inv_depth.
+__global__ __launch_bounds__(256) void rigid_flow_kernel(const float* __restrict__ inv_depth, const float* __restrict__ cam,
+                                                         float* __restrict__ flow, int batch, int h, int w) {
+    const int L = h * w;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * L) return;
+    const int b = (int)(i / L), p = (int)(i - (long)b * L);
+    const int y = p / w, x = p - y * w;
+    const float* cm = cam + (long)b * 30;
+    const float gx = (float)x, gy = (float)y;
+    const float z = 1.0f / inv_depth[i];
+    const float r0 = (cm[0] * gx + cm[1] * gy + cm[2]) * z, r1 = (cm[3] * gx + cm[4] * gy + cm[5]) * z, r2 = (cm[6] * gx + cm[7] * gy + cm[8]) * z;
+    const float X = cm[9] * r0 + cm[10] * r1 + cm[11] * r2 + cm[18];
+    const float Y = cm[12] * r0 + cm[13] * r1 + cm[14] * r2 + cm[19];
+    const float Z = cm[15] * r0 + cm[16] * r1 + cm[17] * r2 + cm[20];
+    const float u = cm[21] * X + cm[22] * Y + cm[23] * Z, v = cm[24] * X + cm[25] * Y + cm[26] * Z;
+    const float zz = fmaxf(cm[27] * X + cm[28] * Y + cm[29] * Z, 1e-3f);
+    flow[((long)b * 2) * L + p] = u / zz - gx;
+    flow[((long)b * 2 + 1) * L + p] = v / zz - gy;
+}
+
+extern "C" int um_rigid_flow(const float* inv_depth, const float* cam, float* flow, int batch, int h, int w, void* stream) {
+    if (!inv_depth || !cam || !flow || batch <= 0 || h <= 0 || w <= 0) {
+        um_set_error("um_rigid_flow: null pointer or non-positive size");
+        return -1;
+    }
+    const long total = (long)batch * h * w;
+    hipLaunchKernelGGL(rigid_flow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_depth, cam, flow, batch, h, w);
+    return (int)hipGetLastError();
+}

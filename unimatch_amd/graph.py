@@ -48,9 +48,6 @@ class GraphedUniMatch(torch.nn.Module):
             return self.model(img0, img1, **kw)
         key = (tuple(img0.shape), tuple(img1.shape), str(img0.dtype), tuple(sorted((k, _freeze(v)) for k, v in kw.items())))
         entry = self._graphs.get(key)
-        if entry is None and (kw.get('task') == 'depth' or torch.is_tensor(kw.get('pose'))):
-            # the depth path inverts intrinsics / poses (torch.inverse synchronises): known not to be capturable, never tried
-            entry = self._graphs[key] = False
         if entry is None:
             try:
                 entry = self._capture(img0, img1, kw)

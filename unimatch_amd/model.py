@@ -452,7 +452,10 @@ class UniMatch(nn.Module):
                     k_cur = intrinsics.clone()
                     k_cur[:, :2] = k_cur[:, :2] / up
                 if s > 0:
-                    flow = F.interpolate(flow, scale_factor=2, mode='bilinear', align_corners=True) * 2
+                    if hasattr(ops, 'flow_upsample2x') and flow.is_cuda:
+                        flow = ops.flow_upsample2x(flow, 2.0)          # unimatch.py:162-163 on um_flow_upsample2x
+                    else:
+                        flow = F.interpolate(flow, scale_factor=2, mode='bilinear', align_corners=True) * 2
                 tok1 = ori1
                 if flow is not None:
                     assert task != 'depth'
@@ -477,13 +480,18 @@ class UniMatch(nn.Module):
                 # ---- matching layer
                 if task == 'depth':
                     cand = self._depth_candidates(min_depth, max_depth, num_depth_candidates, dev)
-                    f0c, f1c, kc, pc = tok0, tok1, k_cur, pose
+                    f0c, f1c = tok0, tok1
                     if pred_bidir_depth:
                         f0c, f1c = torch.cat([tok0, tok1], 0), torch.cat([tok1, tok0], 0)
-                        kc = k_cur.repeat(2, 1, 1)
-                        pc = torch.cat([pose, torch.inverse(pose)], 0)
-                    cam = torch.cat([torch.inverse(kc).flatten(1), pc[:, :3, :3].flatten(1), pc[:, :3, 3],
-                                     kc.flatten(1)], 1).float().contiguous()
+                    if hasattr(ops, 'depth_cam') and tok0.is_cuda:     # K / up, K^-1, (inverse) pose packed on the device, no sync
+                        cam = ops.depth_cam(intrinsics, pose, float(up), pred_bidir_depth)
+                    else:
+                        kc, pc = k_cur, pose
+                        if pred_bidir_depth:
+                            kc = k_cur.repeat(2, 1, 1)
+                            pc = torch.cat([pose, torch.inverse(pose)], 0)
+                        cam = torch.cat([torch.inverse(kc).flatten(1), pc[:, :3, :3].flatten(1), pc[:, :3, 3],
+                                         kc.flatten(1)], 1).float().contiguous()
                     flow_pred = ops.depth_corr_softmax(f0c, f1c, h, w, cam, cand.contiguous(), depth_from_argmax)
                 else:
                     radius = corr_radius_list[s]
@@ -540,10 +548,14 @@ class UniMatch(nn.Module):
                         disp = torch.cat([-flow, torch.zeros_like(flow)], 1)
                     elif task == 'depth':
                         if pred_bidir_depth and it == 0:
-                            k_cur = k_cur.repeat(2, 1, 1)
-                            pose_r = torch.cat([pose, torch.inverse(pose)], 0)
                             ori0, ori1 = torch.cat([ori0, ori1], 0), torch.cat([ori1, ori0], 0)
-                        disp = _rigid_flow(1. / flow.squeeze(1), k_cur, pose_r)
+                        if hasattr(ops, 'rigid_flow') and flow.is_cuda:     # geometry.py:99-195 on um_rigid_flow (cam from the matching layer)
+                            disp = ops.rigid_flow(flow, cam)
+                        else:
+                            if pred_bidir_depth and it == 0:
+                                k_cur = k_cur.repeat(2, 1, 1)
+                                pose_r = torch.cat([pose, torch.inverse(pose)], 0)
+                            disp = _rigid_flow(1. / flow.squeeze(1), k_cur, pose_r)
                     else:
                         disp = flow
                     if nhwc is not None:

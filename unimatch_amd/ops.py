@@ -332,6 +332,38 @@ class HipOps:
         _abi.check(code, 'um_flow_warp')
         return out
 
+    def flow_upsample2x(self, flow, mult=2.0):
+        """``mult * F.interpolate(flow, scale_factor=2, mode='bilinear', align_corners=True)`` (``um_flow_upsample2x``)."""
+        if not (flow.is_cuda and flow.dtype == torch.float32 and flow.dim() == 4):
+            raise ValueError('flow_upsample2x: expected a CUDA float32 [B, V, h, w] tensor')
+        flow = flow.contiguous()
+        b, v, h, w = flow.shape
+        out = torch.empty((b, v, 2 * h, 2 * w), dtype=torch.float32, device=flow.device)
+        _abi.check(self.lib.um_flow_upsample2x(_ptr(flow), _ptr(out), b, v, h, w, float(mult), _stream()), 'um_flow_upsample2x')
+        return out
+
+    def depth_cam(self, intrinsics, pose, stride_div, bidir=False):
+        """``[B or 2B, 30]`` = K^-1 | R | t | K of the depth kernels from the caller's intrinsics ``[B,3,3]`` (rows 0-1 divided by
+        ``stride_div``) and pose ``[B,4,4]`` (``um_depth_cam_pack``; with ``bidir`` the second half carries the inverse pose)."""
+        b = intrinsics.shape[0]
+        if not (tuple(intrinsics.shape) == (b, 3, 3) and tuple(pose.shape) == (b, 4, 4) and intrinsics.is_cuda and pose.is_cuda):
+            raise ValueError('depth_cam: expected CUDA intrinsics [B,3,3] and pose [B,4,4]')
+        k, p = intrinsics.float().contiguous(), pose.float().contiguous()
+        cam = torch.empty((2 * b if bidir else b, 30), dtype=torch.float32, device=k.device)
+        _abi.check(self.lib.um_depth_cam_pack(_ptr(k), _ptr(p), _ptr(cam), b, float(stride_div), int(bool(bidir)), _stream()),
+                   'um_depth_cam_pack')
+        return cam
+
+    def rigid_flow(self, inv_depth, cam):
+        """Flow induced by inverse depth ``[B,1,h,w]`` and ``cam [B,30]`` (``um_rigid_flow``, geometry.py:99-195)."""
+        b, _, h, w = inv_depth.shape
+        if not (inv_depth.is_cuda and inv_depth.dtype == torch.float32 and tuple(cam.shape) == (b, 30)):
+            raise ValueError('rigid_flow: expected CUDA float32 inv_depth [B,1,h,w] and cam [B,30]')
+        inv_depth = inv_depth.contiguous()
+        out = torch.empty((b, 2, h, w), dtype=torch.float32, device=inv_depth.device)
+        _abi.check(self.lib.um_rigid_flow(_ptr(inv_depth), _ptr(cam), _ptr(out), b, h, w, _stream()), 'um_rigid_flow')
+        return out
+
     # ------------------------------------------------------------------ encoder helper (outside the hot path)
     def instance_norm(self, x, relu=True, shortcut=None, eps=1e-5):
         """Fused InstanceNorm2d(affine=False) [+ ReLU] [+ shortcut, ReLU] on a contiguous NCHW fp32 map."""
