@@ -95,6 +95,10 @@ long um_census_count(int variant);
  * 8 waves): the sustained matrix-pipe rate of this part under its power limit, with one constant operand value or with
  * pseudo-random operands (data toggling costs clock).  sink: any device float. */
 int um_debug_mfma_peak(float* sink, int iters, int random_operands, void* stream);
+/* Diagnostic: the same loop with s_memtime stamps -- 256 workgroups of `waves` (4 | 8) waves, 8 * iters MFMAs per wave, on one accumulator
+ * (`chain`) or four; ticks[256 * waves] receives every wave's elapsed s_memtime ticks.  With the host's wall time of the launch this
+ * calibrates the tick rate and the ticks per MFMA the attention kernel's section stamps are read against (tools/mfma_ticks.py). */
+int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int iters, int random_operands, int waves, int chain, void* stream);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 

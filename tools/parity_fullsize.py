@@ -282,6 +282,9 @@ def main():
                       f'{s_["gate"]}  census {group[0]["census"]}' + (f'  [bf16 mode: {fast:.3e}]' if fast is not None else ''), flush=True)
                 rows += group
                 table.append(dict(s_, config=cfg, weights=which, batch=nb(cfg), bf16_gpu_mean=fast))
+                if a.out:                                  # after every group: a run cut short still leaves its rows
+                    with open(a.out, 'w') as fh:
+                        json.dump({'summary': table, 'cases': rows}, fh, indent=1)
     finally:
         legs.close()
     if a.out:

@@ -41,3 +41,61 @@ extern "C" int um_debug_mfma_peak(float* sink, int iters, int random_operands, v
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 4), dim3(512), 0, (hipStream_t)stream, sink, iters, random_operands ? -1.0f : 0.5f);
     return (int)hipGetLastError();
 }
+
+// Calibration of s_memtime against the matrix pipe: the same loop, one workgroup per CU of WAVES waves (4 = one wave per SIMD, 8 =
+// two), every wave stamping s_memtime before and after its MFMAs.  With the kernel's wall time (host events) this gives, in one
+// measurement, the tick rate of s_memtime under this load and the ticks one wave spends per MFMA -- the numbers the section stamps of
+// the attention kernel (tools/trace_attn.py) have to be read against.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfma_ticks_kernel(unsigned long long* ticks, float* sink, int iters, float seed, int chain) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    i16x8 a, b;
+    unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        x = x * 1664525u + 1013904223u;
+        const float va = seed < 0.f ? ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) : seed;
+        x = x * 1664525u + 1013904223u;
+        const float vb = seed < 0.f ? ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) : seed;
+        a[j] = (short)Fp16::down(va);
+        b[j] = (short)Fp16::down(vb);
+    }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (chain) {                                   // all MFMAs on ONE accumulator (the QK^T chain of the attention kernel)
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0] = Fp16::mfma(a, b, acc[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0] = Fp16::mfma(b, a, acc[0]);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = Fp16::mfma(a, b, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = Fp16::mfma(b, a, acc[i]);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
+    if (s == 12345.678f) sink[0] = s;
+}
+
+extern "C" int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int iters, int random_operands, int waves, int chain, void* stream) {
+    const float seed = random_operands ? -1.0f : 0.5f;
+    if (waves == 8)
+        hipLaunchKernelGGL(mfma_ticks_kernel<8>, dim3(256), dim3(512), 0, (hipStream_t)stream, ticks, sink, iters, seed, chain);
+    else
+        hipLaunchKernelGGL(mfma_ticks_kernel<4>, dim3(256), dim3(256), 0, (hipStream_t)stream, ticks, sink, iters, seed, chain);
+    return (int)hipGetLastError();
+}
