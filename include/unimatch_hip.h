@@ -99,6 +99,9 @@ int um_debug_mfma_peak(float* sink, int iters, int random_operands, void* stream
  * (`chain`) or four; ticks[256 * waves] receives every wave's elapsed s_memtime ticks.  With the host's wall time of the launch this
  * calibrates the tick rate and the ticks per MFMA the attention kernel's section stamps are read against (tools/mfma_ticks.py). */
 int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int iters, int random_operands, int waves, int chain, void* stream);
+/* Diagnostic: the attention kernel's QK^T pattern alone -- 256 workgroups of 4 waves, per "tile" 16 ds_read_b128 two k-steps ahead of the 24
+ * MFMAs they feed (mode 0), or the same stream with the MFMAs on loop-invariant A registers (mode 1); ticks[1024]. */
+int um_debug_mfma_lds(unsigned long long* ticks, float* sink, int tiles, int mode, void* stream);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 

@@ -31,3 +31,19 @@ for waves in (4, 8):
             print(f'{waves // 4} wave(s)/SIMD  {"random  " if rnd else "constant"}  {"1 accumulator " if chain else "4 accumulators"}: '
                   f'{ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  tick rate {t / ms / 1e6:5.2f} GHz  {t / n:6.2f} ticks per MFMA and wave  '
                   f'{ms * 1e6 / n * (4.0 / waves) * (waves / 4):6.2f} ns per MFMA and wave', flush=True)
+
+for mode, what in ((0, 'A fragments from LDS (QK^T pattern)'), (1, 'same stream, MFMAs on fixed A registers')):
+    tiles = 20000
+    ticks = torch.zeros(1024, dtype=torch.int64, device='cuda')
+    lib.um_debug_mfma_lds(ticks.data_ptr(), sink.data_ptr(), 500, mode, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.um_debug_mfma_lds(ticks.data_ptr(), sink.data_ptr(), tiles, mode, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    t = ticks.double().mean().item()
+    n = 24.0 * tiles
+    print(f'1 wave(s)/SIMD  LDS-fed   {what}: {ms:8.3f} ms  {1024 * n * 32768 / ms / 1e9:7.1f} TFLOP/s  tick rate {t / ms / 1e6:5.2f} GHz  '
+          f'{t / n:6.2f} ticks per MFMA and wave', flush=True)

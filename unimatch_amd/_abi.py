@@ -23,6 +23,7 @@ SIGNATURES = {
     'um_version': (_c_int, []),
     'um_last_error_string': (ctypes.c_char_p, []),
     'um_debug_mfma_peak': (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p]),
+    'um_debug_mfma_lds': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     'um_debug_mfma_ticks': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     'um_timing_enable': (_c_int, [_c_int]),
     'um_timing_collect': (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),

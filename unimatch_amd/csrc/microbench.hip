@@ -99,3 +99,77 @@ extern "C" int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int i
         hipLaunchKernelGGL(mfma_ticks_kernel<4>, dim3(256), dim3(256), 0, (hipStream_t)stream, ticks, sink, iters, seed, chain);
     return (int)hipGetLastError();
 }
+
+// The attention kernel's QK^T pattern in isolation: per k-step two A fragments come from LDS (ds_read_b128, issued two k-steps ahead)
+// and feed three MFMAs against register-resident B fragments, 24 MFMAs per "tile" on one accumulator.  mode 0: as described; mode 1:
+// the same instruction stream but the MFMAs use loop-invariant A registers (the LDS reads still happen): separates "operands arrive
+// from LDS" from "LDS instructions sit in the stream".
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mfma_lds_kernel(unsigned long long* ticks, float* sink, int tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 65536 / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = 0x3c003800u + (unsigned)(i * 2654435761u >> 20);
+    __syncthreads();
+    i16x8 q[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) q[p][ks] = *reinterpret_cast<const i16x8*>(lds + ((lane * 16 + ks * 1024 + p * 8192) & 65535));
+    int koff[8];
+    const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const i16x8 fixh = q[0][0], fixl = q[1][0];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < tiles; ++t) {
+        const unsigned char* kb = lds + (t & 1) * 16384;
+        i16x8 fh[3], fl[3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fh[ks] = *reinterpret_cast<const i16x8*>(kb + koff[ks]);
+            fl[ks] = *reinterpret_cast<const i16x8*>(kb + 8192 + koff[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 2 < 8) {
+                fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + koff[ks + 2]);
+                fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + 8192 + koff[ks + 2]);
+            }
+            if (MODE == 0) {
+                acc = Fp16::mfma(fl[ks % 3], q[0][ks], acc);
+                acc = Fp16::mfma(fh[ks % 3], q[1][ks], acc);
+                acc = Fp16::mfma(fh[ks % 3], q[0][ks], acc);
+            } else {
+                acc = Fp16::mfma(fixl, q[0][ks], acc);
+                acc = Fp16::mfma(fixh, q[1][ks], acc);
+                acc = Fp16::mfma(fixh, q[0][ks], acc);
+                asm volatile("" : : "v"(fh[ks % 3]), "v"(fl[ks % 3]));        // the reads stay
+            }
+        }
+        constexpr int RD = 2, MF = 3;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) ticks[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+    if (s == 12345.678f) sink[0] = s;
+}
+
+extern "C" int um_debug_mfma_lds(unsigned long long* ticks, float* sink, int tiles, int mode, void* stream) {
+    if (mode == 0)
+        hipLaunchKernelGGL(mfma_lds_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, ticks, sink, tiles);
+    else
+        hipLaunchKernelGGL(mfma_lds_kernel<1>, dim3(256), dim3(256), 0, (hipStream_t)stream, ticks, sink, tiles);
+    return (int)hipGetLastError();
+}

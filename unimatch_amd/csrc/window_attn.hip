@@ -818,9 +818,10 @@ static int wattn_key_split(int total, int ntiles) {
 // 0.2403 ms: the first launch's workgroups do not finish together and the launch boundary idles the early finishers' slots);
 // 256-query / 8-wave workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time, worse quantisation);
 // a software-pipelined one-wave-per-SIMD instantiation with Q^T and O^T in AGPRs (0.293 against 0.260 ms); alternating
-// accumulators in QK^T / PV (0.262 against 0.241 ms).  What the section stamps of those builds showed: a lone wave issues one
-// 32x32x16 MFMA per ~45 cycles whatever sits between them (the power-limited rate, 1.72 PFLOP/s chip-wide on such operands),
-// and the two waves a SIMD holds keep the pipe at 85 % of THAT rate during the full round; the loss is the tail round.
+// accumulators in QK^T / PV (0.262 against 0.241 ms).  What the section stamps of those builds showed (calibrated by tools/mfma_ticks.py):
+// VALU between the MFMAs is free and dependent MFMA chains issue at the full rate; a lone wave's MFMA phases run at 45.6 cycles per
+// MFMA (32 + LDS operand stream + the LDS-DMA statements inside the phase), the two waves a SIMD holds keep the pipe ~60 % busy in
+// the full round, the third group of workgroups (one wave per SIMD) 37 %.
 struct WattnPlan {
     int full;       // tiles served one workgroup each (0: none)
     int rem;        // tiles served key-split (0: none)
