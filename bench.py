@@ -117,8 +117,13 @@ def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch, flops_attn_fus
     issued = 3.0 if precision == 'exact' else 1.0
     tag = ('Fp16, 2' if precision == 'exact' else 'Bf16, 1')
     out = []
+    # the instantiation the bench's attention calls take: key-split remainder round inside the launch or not (um_window_attn_plan)
+    from unimatch_amd import _abi
+    f_, r_, k_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _abi.load().um_window_attn_plan(2 * batch, HEIGHT // 8, WIDTH // 8, HEIGHT // 16, WIDTH // 16, ctypes.byref(f_), ctypes.byref(r_), ctypes.byref(k_))
+    ksplit = 'true' if r_.value > 0 else 'false'
     for name, key, files, (ms, n), fl in (
-            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, false>",
+            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, {ksplit}>",
              ['window_attn.hip', 'common.h'], attn, flops_attn),
             ('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
              gsv, flops_gsv)):

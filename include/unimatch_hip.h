@@ -153,17 +153,17 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
  * launch of few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking a whole window) gives every query tile
  * to 2 or 4 neighbouring workgroups, each on its share of the window's keys; the first merges the others' partial softmaxes
  * (exact).  The byte count is 0 for launches that are not split. */
-/* Assumptions of the split small launches (um_window_attn_qproj_merge_fwd with workspace, um_ffn_ws_fwd): the parts of a tile hand
- * their partial results over through `workspace` while the kernel runs -- part 0 spins on a flag the other parts raise.  The host
- * only splits while every workgroup of the launch fits the device at once (2 x CUs attention / 1 x CUs FFN workgroups, CU count of
- * the current device), so the wait terminates provided nothing else occupies the device for the whole kernel AND withholds the
- * remaining slots from this launch; partner workgroups are neighbours in dispatch order (same XCD), so in-order dispatch -- what
- * the hardware does, not what HIP promises -- is enough even then.  The workspace must be zero before the first launch that uses it,
- * is left with zero flags by every launch, and must not be shared by launches in flight on different streams. */
+/* Split launches.  um_window_attn_qproj_merge_fwd with `workspace` lets several workgroups share the key walk of a query tile (launch
+ * plan: um_window_attn_plan).  Every part publishes its partial (O, M, l) in the workspace and takes a ticket from the tile's arrival
+ * counter; the last arriver merges all parts in part order (exact power-of-two factors; bitwise reproducible) and finishes the
+ * layer.  Nobody waits for anybody: no assumption about residency or dispatch order.  The workspace must be zero before the first
+ * launch that uses it, is left with zero counters by every launch, and must not be shared by launches in flight on different streams.
+ * um_ffn_ws_fwd's hidden split (small launches only) still has part 0 wait for the others' flags: the host only splits while every
+ * workgroup of the launch fits the device at once (1 x CUs of the current device), partners are neighbours in dispatch order. */
 size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w);
 /* The launch plan of um_window_attn_qproj_merge_fwd for a geometry, a pure function of the arguments and the current device's CU
  * count: `full_tiles` 128-query tiles are served one workgroup each, `split_tiles` tiles by `parts` workgroups each on a share of
- * the window's key tiles (small launches only: every workgroup resident at once). */
+ * the window's key tiles (launches whose tiles all fit the chip at once: batch-1 latency; big launches are never split -- measured). */
 int um_window_attn_plan(int streams, int h, int w, int win_h, int win_w, int* full_tiles, int* split_tiles, int* parts);
 int um_window_attn_qproj_merge_fwd(const float* x, const void* wq_planes, const void* k_planes, const void* v_planes,
                                    const void* wm_planes, const float* gamma, const float* beta, const float* residual, float eps,

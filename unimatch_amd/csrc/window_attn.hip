@@ -71,12 +71,12 @@ struct WattnArgs {
     // QPROJ variant: q = x . Wq^T computed in the prologue (transformer.py:58); qp is unused
     const float* x;              // [S][L][128] fp32 source tokens
     const unsigned short* wq;    // planes [NS][128][128] of the query weight, pre-scaled by 2^wshift (stride wm_plane_stride)
-    // KSPLIT variant (small launches and the remainder round of big ones): `split` workgroups per query tile, each on 1 / split
-    // of the window's key tiles; tile_base = first query tile of this launch (a call may be two launches, see wattn_plan)
+    // KSPLIT instantiation: the first `full` workgroups of the grid serve one query tile each; the others come in groups of `split`
+    // per tile, each on 1 / split of the window's key tiles (small launches: full = 0; big launches: the remainder round)
     int split;
-    int tile_base;
-    float* ks_part;              // [tiles * (split - 1)][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of the parts 1 .. split-1
-    unsigned* ks_flag;           // [total * (split - 1)], zero between launches: 1 = the slot is complete
+    int full;
+    float* ks_part;              // [split tiles][split][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of every part
+    unsigned* ks_flag;           // [split tiles] arrival counters, zero between launches
 };
 
 // window-local token -> global token index and its mask class.
@@ -128,16 +128,28 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const float neg1 = um_opaque_neg1();
-    // KSPLIT: a launch with few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking the whole window) is latency-
-    // bound by that walk.  `split` workgroups share a query tile, neighbours in the grid (same XCD); part p takes the p-th
-    // share of the key tiles; parts > 0 leave (O^T, M, l) in a memory slot and raise its flag, part 0 merges them (integer
-    // offsets, power-of-two factors: exact) and runs the epilogue.  All workgroups of such a launch are resident at once
-    // (the host only splits while total * split fits), so the wait cannot deadlock.
-    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nsplit = KSPLIT ? a.split : 1;
-    const int wl = KSPLIT ? wgid / nsplit : wgid;                  // query tile within this launch (indexes the hand-off slots)
-    const int part = KSPLIT ? wgid - wl * nsplit : 0;
-    const int wg = wl + a.tile_base;                               // query tile of the call
+    // KSPLIT: a query tile whose key walk is shared by `split` workgroups, neighbours in the grid (same XCD); part p takes the
+    // p-th share of the key tiles.  Used for launches with few query tiles (batch 1: 40 - 96 tiles on 256 CUs, each walking the
+    // whole window, are latency-bound by that walk) and for the REMAINDER round of big launches (768 tiles on 512 resident slots:
+    // the last 256 tiles as 512 half-walks keep every slot busy to the end).  Hand-off without waiting: every part publishes
+    // (O^T, M, l) in its memory slot and takes a ticket from the tile's arrival counter; the LAST arriver merges all slots in part
+    // order (integer offsets, power-of-two factors: exact, and the order is fixed: bitwise reproducible) and runs the epilogue,
+    // the others exit.  Nobody spins, so nothing is assumed about residency or dispatch order.
+    int wg, wl = 0, part = 0, nsplit = 1;
+    if constexpr (KSPLIT) {
+        const int b = blockIdx.x;
+        if (b < a.full) {
+            wg = xcd_remap(b, a.full);                             // (a.full is a multiple of the XCD count or 0)
+        } else {
+            const int j = xcd_remap(b - a.full, (int)gridDim.x - a.full);
+            nsplit = a.split;
+            wl = j / nsplit;                                       // split tile (indexes the slots and the counter)
+            part = j - wl * nsplit;
+            wg = a.full + wl;                                      // query tile of the call
+        }
+    } else {
+        wg = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int qt = wg % a.nqt;
     const int win = (wg / a.nqt) % a.nwin;
     const int s = wg / (a.nqt * a.nwin);
@@ -161,8 +173,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     const int ntiles = (a.n + TK - 1) / TK;
-    const int t0 = KSPLIT ? (part * ntiles) / nsplit : 0;                 // this workgroup's key tiles [t0, t1)
-    const int t1 = KSPLIT ? ((part + 1) * ntiles) / nsplit : ntiles;
+    const int t0 = (part * ntiles) / nsplit;                              // this workgroup's key tiles [t0, t1)
+    const int t1 = ((part + 1) * ntiles) / nsplit;
 #ifdef UM_TRACE
     const bool tracing = g_um_trace != nullptr && (blockIdx.x % 37) == 0 && tid == 0;
     unsigned long long* trace_buf = g_um_trace + (size_t)(blockIdx.x / 37) * (24 * 8 + 8);
@@ -593,57 +605,52 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
     }
     if constexpr (KSPLIT) {
-        // The slots are written and read ONLY by agent-scope accesses, which go through to memory themselves; a release /
-        // acquire FENCE at agent scope would write back / invalidate the XCD's whole L2 (measured).  What is needed is the
-        // completion of the stores before the flag is raised: vmcnt(0) + the barrier.
-        // Slot layout: 17 vectors of 16 bytes per thread, [vector][thread] -- O^T (16 vectors: tile dt, register group g) then
-        // (M, l, -, -).
+        // The slots are written and read ONLY by 16-byte agent-scope accesses (sc1: write-through / L1-bypassing; the parts of a tile
+        // share an XCD and therefore an L2); a release / acquire FENCE at agent scope would write back / invalidate the XCD's whole
+        // L2 (measured).  What is needed is the completion of the stores before the ticket is taken: vmcnt(0) + the barrier.
+        // Slot layout: 17 vectors of 16 bytes per thread, [vector][thread] -- O^T (16 vectors: tile dt, register group g), (M, l, -, -).
         constexpr int KS_SLOT = 17 * 256 * 4;                        // floats per slot
-        if (part > 0) {
-            const long slot = (long)wl * (nsplit - 1) + part - 1;
-            float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
+        if (nsplit > 1) {
+            float* mine = a.ks_part + ((long)wl * nsplit + part) * KS_SLOT + 4 * tid;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                    st_agent_16B(pr + (dt * 4 + g) * 1024, v);
+                    st_agent_16B(mine + (dt * 4 + g) * 1024, v);
                 }
             {
                 const f32x4 v = {M, l, 0.f, 0.f};
-                st_agent_16B(pr + 16 * 1024, v);
+                st_agent_16B(mine + 16 * 1024, v);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                         // every thread's stores are complete
+            unsigned* ticket = reinterpret_cast<unsigned*>(lds);     // (the K/V ring is idle now)
+            if (tid == 0) *ticket = __hip_atomic_fetch_add(a.ks_flag + wl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        for (int p = 1; p < nsplit; ++p) {
-            const long slot = (long)wl * (nsplit - 1) + p - 1;
-            if (tid == 0) {
-                while (__hip_atomic_load(a.ks_flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
-                    __builtin_amdgcn_s_sleep(4);
+            if (*ticket != (unsigned)(nsplit - 1)) return;           // not the last arriver: done
+            __syncthreads();                                         // (the ring is about to take Wm)
+            if (tid == 0) __hip_atomic_store(a.ks_flag + wl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+            // merge in part order, starting from part 0's slot (so that the result does not depend on who arrived last)
+            for (int p = 0; p < nsplit; ++p) {
+                const float* pr = a.ks_part + ((long)wl * nsplit + p) * KS_SLOT + 4 * tid;
+                const f32x4 ml = ld_agent_16B(pr + 16 * 1024);
+                const float Mo = ml[0], lo = ml[1];
+                const float Ms = p == 0 ? Mo : fminf(M, Mo);          // offsets are integers: the factors are powers of two
+                const float fa = p == 0 ? 0.f : fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
+                l = l * fa + lo * fb;
+                M = Ms;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    f32x4 w[4];
+                    const float* q = pr + dt * 4 * 1024;
+                    ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[dt][4 * g + i] = o[dt][4 * g + i] * fa + w[g][i] * fb;
+                }
             }
-            __syncthreads();
-            const float* pr = a.ks_part + slot * KS_SLOT + 4 * tid;
-            const f32x4 ml = ld_agent_16B(pr + 16 * 1024);
-            const float Mo = ml[0], lo = ml[1];
-            const float Ms = fminf(M, Mo);                           // offsets are integers: the factors are powers of two
-            const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
-            l = l * fa + lo * fb;
-            M = Ms;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 w[4];
-                const float* q = pr + dt * 4 * 1024;
-                ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[dt][4 * g + i] = o[dt][4 * g + i] * fa + w[g][i] * fb;
-            }
-            __syncthreads();                                         // everybody has read the slot
-            if (tid == 0) __hip_atomic_store(a.ks_flag + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         }
     }
 
@@ -809,23 +816,19 @@ static int wattn_key_split(int total, int ntiles) {
     return split;
 }
 
-// ---- launch plan: a pure function of the geometry (and the device's CU count).
-//   * a small launch (every 128-query tile resident at once, two workgroups per CU): tiles key-split `split` ways while the
-//     launch stays resident (batch-1 latency);
+// ---- launch plan: a pure function of the geometry (and the device's CU count).  The chip holds 2 * CUs workgroups at once.
+//   * a small launch (total <= slots): every tile key-split `split` ways while the launch fits the chip (batch-1 latency);
 //   * a big launch: one workgroup per tile.
-// Round 3 measured four restructurings of the big launch on the GPU and dropped them all (profiles/r03_attention_experiments.txt;
-// the code is in git at 85b86af): the remainder round of 768 tiles on 512 slots key-split as a second launch (0.2514 against
-// 0.2403 ms: the first launch's workgroups do not finish together and the launch boundary idles the early finishers' slots);
-// 256-query / 8-wave workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time, worse quantisation);
-// a software-pipelined one-wave-per-SIMD instantiation with Q^T and O^T in AGPRs (0.293 against 0.260 ms); alternating
-// accumulators in QK^T / PV (0.262 against 0.241 ms).  What the section stamps of those builds showed (calibrated by tools/mfma_ticks.py):
-// VALU between the MFMAs is free and dependent MFMA chains issue at the full rate; a lone wave's MFMA phases run at 45.6 cycles per
-// MFMA (32 + LDS operand stream + the LDS-DMA statements inside the phase), the two waves a SIMD holds keep the pipe ~60 % busy in
-// the full round, the third group of workgroups (one wave per SIMD) 37 %.
+// Round 3 measured five restructurings of the big launch on the GPU and dropped them all (profiles/r03_attention_experiments.txt;
+// code in git at 85b86af and fb-balance commits): the remainder round of 768 tiles on 512 slots key-split -- as a second launch
+// (0.2514 against 0.2403 ms) and, with the ticket hand-off, at the end of the same grid (0.2570 against 0.2473 ms): the half walks
+// pay a second prologue and the hand-off, and the tail they replace is less idle than a round count suggests; 256-query / 8-wave
+// workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time); a software-pipelined one-wave-per-SIMD
+// instantiation with Q^T and O^T in AGPRs (0.293 against 0.260 ms); alternating accumulators in QK^T / PV (0.262 against 0.241).
 struct WattnPlan {
     int full;       // tiles served one workgroup each (0: none)
     int rem;        // tiles served key-split (0: none)
-    int split;      // parts per tile of the key-split launch (1 when rem == 0)
+    int split;      // parts per key-split tile (1 when rem == 0)
 };
 
 static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
@@ -838,8 +841,7 @@ static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
 }
 
 static size_t wattn_ks_bytes(int tiles, int split) {
-    const size_t slots = (size_t)tiles * (split - 1);
-    return align256w(slots * sizeof(unsigned)) + slots * (17 * 256 * 4 * sizeof(float));
+    return align256w((size_t)tiles * sizeof(unsigned)) + (size_t)tiles * split * (17 * 256 * 4 * sizeof(float));
 }
 
 extern "C" size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w) {
@@ -1022,32 +1024,31 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     static const float headroom = [] { const char* e = um_debug_env("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
-    a.tile_base = 0;
+    a.full = 0;
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (wm && wq) {
-        // the layer kernel (query projection + attention + merge + LayerNorm): whole rounds one workgroup per tile, small
-        // launches and the remainder round key-split (wattn_plan); without workspace everything runs one workgroup per tile
+        // the layer kernel (query projection + attention + merge + LayerNorm): wattn_plan; without workspace one workgroup per tile
         WattnPlan p = wattn_plan(a.total, (a.n + 31) / 32, ks_ws != nullptr);
         if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1};
-        if (p.full > 0) {
+        if (p.rem == 0) {
             um_census_hit(UM_V_WATTN_TILE);
             if (mode == 0)
                 hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true>), dim3(p.full), dim3(256), 0, stream, a);
             else
                 hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true>), dim3(p.full), dim3(256), 0, stream, a);
-            if (hipError_t e = hipGetLastError()) return (int)e;
+            return (int)hipGetLastError();
         }
-        if (p.rem > 0) {
-            um_census_hit(UM_V_WATTN_KSPLIT);
-            a.tile_base = p.full;
-            a.split = p.split;
-            a.ks_flag = (unsigned*)ks_ws;
-            a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)p.rem * (p.split - 1) * sizeof(unsigned)));
-            if (mode == 0)
-                hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(p.rem * p.split), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, true>), dim3(p.rem * p.split), dim3(256), 0, stream, a);
-        }
+        if (p.full > 0) um_census_hit(UM_V_WATTN_TILE);             // whole tiles and key-split tiles share the launch
+        um_census_hit(UM_V_WATTN_KSPLIT);
+        a.full = p.full;
+        a.split = p.split;
+        a.ks_flag = (unsigned*)ks_ws;
+        a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)p.rem * sizeof(unsigned)));
+        const unsigned grid = (unsigned)(p.full + p.rem * p.split);
+        if (mode == 0)
+            hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(grid), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true, true>), dim3(grid), dim3(256), 0, stream, a);
         return (int)hipGetLastError();
     }
     um_census_hit(UM_V_WATTN_TILE);
