@@ -153,13 +153,12 @@ int um_window_attn_merge_fwd(const void* q_planes, const void* k_planes, const v
  * launch of few query tiles (batch 1: 40 - 96 workgroups on 256 CUs, each walking a whole window) gives every query tile
  * to 2 or 4 neighbouring workgroups, each on its share of the window's keys; the first merges the others' partial softmaxes
  * (exact).  The byte count is 0 for launches that are not split. */
-/* Split launches.  um_window_attn_qproj_merge_fwd with `workspace` lets several workgroups share the key walk of a query tile (launch
- * plan: um_window_attn_plan).  Every part publishes its partial (O, M, l) in the workspace and takes a ticket from the tile's arrival
- * counter; the last arriver merges all parts in part order (exact power-of-two factors; bitwise reproducible) and finishes the
- * layer.  Nobody waits for anybody: no assumption about residency or dispatch order.  The workspace must be zero before the first
- * launch that uses it, is left with zero counters by every launch, and must not be shared by launches in flight on different streams.
- * um_ffn_ws_fwd's hidden split (small launches only) still has part 0 wait for the others' flags: the host only splits while every
- * workgroup of the launch fits the device at once (1 x CUs of the current device), partners are neighbours in dispatch order. */
+/* Split launches.  um_window_attn_qproj_merge_fwd and um_ffn_ws_fwd with `workspace` let several workgroups share the key walk of a
+ * query tile / the hidden slices of a token tile when the launch is small (launch plans: um_window_attn_plan,
+ * um_ffn_split_workspace_bytes).  Every part publishes its partial result in the workspace and takes a ticket from the tile's arrival
+ * counter; the last arriver combines all parts in part order (exact / fixed order: bitwise reproducible) and finishes the layer.
+ * Nobody waits for anybody: no assumption about residency or dispatch order.  The workspace must be zero before the first launch
+ * that uses it, is left with zero counters by every launch, and must not be shared by launches in flight on different streams. */
 size_t um_window_attn_ksplit_workspace_bytes(int streams, int h, int w, int win_h, int win_w);
 /* The launch plan of um_window_attn_qproj_merge_fwd for a geometry, a pure function of the arguments and the current device's CU
  * count: `full_tiles` 128-query tiles are served one workgroup each, `split_tiles` tiles by `parts` workgroups each on a share of
@@ -215,8 +214,8 @@ int um_ffn_fwd(const float* x, const float* y, const void* w1_planes, const void
 /* The same with an optional workspace of um_ffn_split_workspace_bytes(m, hidden) bytes that are ZERO before the first launch
  * (the kernel leaves them zero; one workspace serves one launch at a time).  With it a launch of few token tiles (batch 1:
  * 35 - 96 workgroups on 256 CUs, each walking all hidden slices) gives every tile to 2 or 4 neighbouring workgroups, each on
- * its share of the hidden units; the first adds the others' partial outputs before LayerNorm.  The byte count is 0 for
- * launches that are not split. */
+ * its share of the hidden units; the last one to finish sums the partial outputs (in part order) before LayerNorm.  The byte
+ * count is 0 for launches that are not split. */
 size_t um_ffn_split_workspace_bytes(int m, int hidden);
 int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
                   int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,

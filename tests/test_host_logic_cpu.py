@@ -244,7 +244,7 @@ def test_small_launch_split_plans_without_gpu():
         return ((tiles * 4 + 255) // 256) * 256 + tiles * split * slot_a
 
     def hs_bytes(tiles, split):
-        return ((tiles * (split - 1) * 4 + 255) // 256) * 256 + tiles * (split - 1) * slot_f
+        return ((tiles * 4 + 255) // 256) * 256 + tiles * split * slot_f
 
     assert ks(16, 64, 96, 32, 48) == 0                           # config 2, batch 8: 768 query tiles, one workgroup each
 

@@ -48,8 +48,8 @@ struct FfnArgs {
     float eps;
     // HSPLIT variant (small launches): `split` workgroups per 128-token tile, each on 1 / split of the hidden slices
     int split;
-    float* hs_part;               // [tiles * (split - 1)][64][256] fp32: the parts' partial O^T (already scaled)
-    unsigned* hs_flag;            // [tiles * (split - 1)], zero between launches: 1 = the slot is complete
+    float* hs_part;               // [tiles][split][16][256][4] fp32: every part's partial O^T (already scaled)
+    unsigned* hs_flag;            // [tiles] arrival counters, zero between launches
 };
 
 __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -138,10 +138,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     const int half = lane >> 5, tl = lane & 31;
     // HSPLIT: at batch 1 the launch has 35 - 96 workgroups on 256 CUs, each walking all 32 hidden slices.  `split`
     // neighbouring workgroups share a token tile; part p walks the p-th share of the hidden slices (the second GEMM is a sum over
-    // hidden units, so the parts' O^T simply add); parts > 0 leave their O^T in a memory slot and raise its flag, part 0 adds
-    // them and runs LayerNorm + residual.  Every workgroup of such a launch is resident at once (the host only splits while
-    // tiles * split fits the CUs), so the wait cannot deadlock.  Slots are touched by agent-scope accesses only (no
-    // agent-scope fence: those write back / invalidate the XCD's whole L2).
+    // hidden units, so the parts' O^T simply add); every part leaves its O^T in a memory slot and takes a ticket, the last
+    // arriver adds the slots in part order and runs LayerNorm + residual (nobody waits; see the epilogue).  Slots are touched by
+    // agent-scope accesses only (no agent-scope fence: those write back / invalidate the XCD's whole L2).
     const int nsplit = HSPLIT ? a.split : 1;
     const int tile_id = HSPLIT ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
     const int part = HSPLIT ? (int)blockIdx.x - tile_id * nsplit : 0;
@@ -468,41 +467,42 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             }
     }
     if constexpr (HSPLIT) {          // all 8 waves stay for the barriers; the role-0 waves (256 threads) carry O^T
+        // Hand-off without waiting (as in window_attn.hip): every part publishes its partial O^T in its memory slot (16-byte
+        // agent-scope stores), takes a ticket from the tile's arrival counter, and the LAST arriver sums all slots in part order
+        // (fixed order: bitwise reproducible) and finishes the layer; the others exit.  Slot: 16 vectors x 256 threads x 16 B.
         const int t4 = 64 * pair + lane;
-        if (part > 0) {
-            const long slot = (long)tile_id * (nsplit - 1) + part - 1;
-            if (role == 0) {
-                float* pr = a.hs_part + slot * (64 * 256) + t4;
+        constexpr int HS_SLOT = 16 * 256 * 4;                      // floats per slot
+        if (role == 0) {
+            float* mine = a.hs_part + ((long)tile_id * nsplit + part) * HS_SLOT + 4 * t4;
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
+            for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        __hip_atomic_store(pr + (ot * 16 + r) * 256, o[ot][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(a.hs_flag + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {o[ot][4 * g], o[ot][4 * g + 1], o[ot][4 * g + 2], o[ot][4 * g + 3]};
+                    st_agent_16B(mine + (ot * 4 + g) * 1024, v);
+                }
         }
-        for (int p = 1; p < nsplit; ++p) {
-            const long slot = (long)tile_id * (nsplit - 1) + p - 1;
-            if (tid == 0) {
-                while (__hip_atomic_load(a.hs_flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
-                    __builtin_amdgcn_s_sleep(4);
-            }
-            __syncthreads();
-            if (role == 0) {
-                const float* pr = a.hs_part + slot * (64 * 256) + t4;
-#pragma unroll
-                for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        o[ot][r] += __hip_atomic_load(pr + (ot * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();                                       // everybody has read the slot
-            if (tid == 0) __hip_atomic_store(a.hs_flag + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // every thread's stores are complete
+        unsigned* ticket = reinterpret_cast<unsigned*>(lds);       // (rings and exchange buffers are dead)
+        if (tid == 0) *ticket = __hip_atomic_fetch_add(a.hs_flag + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*ticket != (unsigned)(nsplit - 1)) return;             // not the last arriver: done
+        if (tid == 0) __hip_atomic_store(a.hs_flag + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         if (role == 1) return;
+        for (int p = 0; p < nsplit; ++p) {
+            const float* pr = a.hs_part + ((long)tile_id * nsplit + p) * HS_SLOT + 4 * t4;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                f32x4 w[4];
+                const float* q = pr + ot * 4 * 1024;
+                ld_agent_16Bx4(q, q + 1024, q + 2048, q + 3072, w[0], w[1], w[2], w[3]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = (p == 0 ? 0.f : o[ot][4 * g + i]) + w[g][i];
+            }
+        }
     }
     float s1 = 0.f;
 #pragma unroll
@@ -565,7 +565,7 @@ static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
     return a.split > 1 ? launch_ffn_impl<T, NS, true>(a, stream) : launch_ffn_impl<T, NS, false>(a, stream);
 }
 
-// ---- hidden split for small launches: only while every workgroup is resident at once (one per CU: 128 KB of LDS each)
+// ---- hidden split for small launches: while tiles x parts fit the chip (one workgroup per CU: 128 KB of LDS each)
 static int ffn_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 static int ffn_hidden_split(int m, int hidden) {
@@ -577,9 +577,9 @@ static int ffn_hidden_split(int m, int hidden) {
     return split;
 }
 
-static size_t ffn_hs_bytes(int m, int split) {
-    const size_t slots = (size_t)((m + 127) / 128) * (split - 1);
-    return ((slots * sizeof(unsigned) + 255) & ~(size_t)255) + slots * (64 * 256 * sizeof(float));
+static size_t ffn_hs_bytes(int m, int split) {                    // arrival counters + one slot per part
+    const size_t tiles = (size_t)((m + 127) / 128);
+    return ((tiles * sizeof(unsigned) + 255) & ~(size_t)255) + tiles * split * (64 * 256 * sizeof(float));
 }
 
 extern "C" size_t um_ffn_split_workspace_bytes(int m, int hidden) {
@@ -631,7 +631,7 @@ extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_plan
     if (workspace) {
         const int split = ffn_hidden_split(m, hidden);
         if (split > 1 && workspace_bytes >= ffn_hs_bytes(m, split)) {
-            const size_t slots = (size_t)((m + 127) / 128) * (split - 1);
+            const size_t slots = (size_t)((m + 127) / 128);       // one arrival counter per tile
             a.split = split;
             a.hs_flag = (unsigned*)workspace;
             a.hs_part = (float*)((unsigned char*)workspace + ((slots * sizeof(unsigned) + 255) & ~(size_t)255));

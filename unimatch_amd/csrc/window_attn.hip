@@ -803,7 +803,7 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                               const float* residual = nullptr, float eps = 0.f, int wshift = 0, const float* x = nullptr,
                               const unsigned short* wq = nullptr, void* ks_ws = nullptr, size_t ks_ws_bytes = 0);
 
-// ---- key split for small launches (see KSPLIT in the kernel): only while every workgroup of the launch is resident at once
+// ---- key split for small launches (see KSPLIT in the kernel): while tiles x parts fit the chip (two workgroups per CU)
 static int wattn_num_cus() { return um_num_cus(); }      // per device (common.h)
 
 static int wattn_key_split(int total, int ntiles) {
@@ -820,7 +820,7 @@ static int wattn_key_split(int total, int ntiles) {
 //   * a small launch (total <= slots): every tile key-split `split` ways while the launch fits the chip (batch-1 latency);
 //   * a big launch: one workgroup per tile.
 // Round 3 measured five restructurings of the big launch on the GPU and dropped them all (profiles/r03_attention_experiments.txt;
-// code in git at 85b86af and fb-balance commits): the remainder round of 768 tiles on 512 slots key-split -- as a second launch
+// code in git at 85b86af; the kernel still takes `full` > 0): the remainder round of 768 tiles on 512 slots key-split -- as a second launch
 // (0.2514 against 0.2403 ms) and, with the ticket hand-off, at the end of the same grid (0.2570 against 0.2473 ms): the half walks
 // pay a second prologue and the hand-off, and the tail they replace is less idle than a round count suggests; 256-query / 8-wave
 // workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time); a software-pipelined one-wave-per-SIMD
