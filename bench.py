@@ -65,7 +65,23 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
     ap.add_argument('--cpu-iters', type=int, default=8)
+    ap.add_argument('--set', action='append', default=[], metavar='Class.attr=value',
+                    help='A/B knob for tools/ab_bench.py: set a class attribute of HipOps / CNNEncoder before the run, e.g. '
+                         'HipOps.fused_merge=0 (the product reads no environment variable)')
     return ap.parse_args()
+
+
+def apply_knobs(specs):
+    from unimatch_amd.encoder import CNNEncoder
+    from unimatch_amd.ops import HipOps
+    classes = {'HipOps': HipOps, 'CNNEncoder': CNNEncoder}
+    for spec in specs:
+        target, _, value = spec.partition('=')
+        cls, _, attr = target.partition('.')
+        if cls not in classes or not hasattr(classes[cls], attr):
+            raise SystemExit(f'bench.py --set: unknown knob {target}')
+        old = getattr(classes[cls], attr)
+        setattr(classes[cls], attr, type(old)(int(value)) if isinstance(old, (bool, int)) else type(old)(value))
 
 
 def collect(lib, kid):
@@ -184,6 +200,7 @@ def main():
 
     from unimatch_amd import UniMatch, _abi
     from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict
+    apply_knobs(args.set)
     ck, fk = CONFIGS['gmflow_s1']
     model = UniMatch(**ck).eval()
     sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()})

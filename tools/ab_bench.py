@@ -2,15 +2,17 @@
 
 MI355X boxes differ by +-5 % in `bench.py` throughput and a kernel's microbenchmark time is not its time inside the model
 (a kernel launched back to back runs hotter and therefore at a lower clock than the same kernel between memory-bound
-neighbours), so every optimisation of round 1 was accepted or dropped on an ABAB run of `bench.py` itself on ONE box:
+neighbours), so every optimisation was accepted or dropped on an ABAB run of `bench.py` itself on ONE box:
 
-    python tools/ab_bench.py --steps 30  A=UM_NO_MERGE=1  B=
     python tools/ab_bench.py  old=UM_LIB=unimatch_amd/_variants/libold.so  new=
+    python tools/ab_bench.py --steps 30  A=--set,HipOps.fused_merge=0  B=
 
-Every argument is `label=ENV1=v1,ENV2=v2` (empty = the tree as it is).  Useful switches: `UM_LIB` (an alternative build of
-the library, e.g. compiled with a -D flag into unimatch_amd/_variants/), `UM_NO_MERGE=1` (merge + LayerNorm as its own
-launch), `UM_CONV_NO_ROWS=1` (generic convolution kernel only), `UM_CONV_NO_XCD=1` (plain workgroup order in the convolutions), `UM_CONV_PATCH=0` (no 2-D patch kernel; digits = tile widths it may serve),
-`UM_SHORTCUT_F32=1` (encoder keeps fp32 copies for the identity shortcuts).  Run-to-run repeatability on one box is ~0.1 %.
+Every argument is `label=SPEC1,SPEC2,...` (empty = the tree as it is).  A SPEC is either `ENV=value` -- `UM_LIB=<path>` loads a
+diagnostic build of the library (`python -m unimatch_amd.build --variant NAME -DFLAG ...` -> unimatch_amd/_variants/libNAME.so;
+with `-DUM_DEBUG_SWITCHES` the library's own A/B switches `UM_GSV_V3`, `UM_CONV_PATCH`, `UM_CONV_NO_ROWS`, `UM_CONV_NO_XCD`,
+`UM_WATTN_NO_KSPLIT`, `UM_FFN_NO_HSPLIT` become live; the shipped library reads no environment variable) -- or a `bench.py`
+argument starting with `--` (`--set,HipOps.fused_merge=0`: merge + LayerNorm as its own launch; `--set,HipOps.fused_qproj=0`;
+`--set,CNNEncoder.shortcut_f32=1`).  Run-to-run repeatability on one box is ~0.1 %.
 """
 import json
 import os
@@ -29,16 +31,28 @@ def main():
         del args[i:i + 2]
     variants = []
     for a in args:
-        label, _, envs = a.partition('=')
-        env = dict(kv.split('=', 1) for kv in envs.split(',') if kv)
-        variants.append((label, env))
+        label, _, specs = a.partition('=')
+        parts = [p for p in specs.split(',') if p]
+        env, extra, i = {}, [], 0
+        while i < len(parts):
+            if parts[i] == '--set' and i + 1 < len(parts):          # bench.py --set Class.attr=value
+                extra += parts[i:i + 2]
+                i += 2
+            elif parts[i].startswith('--'):                          # any other bench.py flag
+                extra.append(parts[i])
+                i += 1
+            else:                                                    # ENV=value
+                k, _, v = parts[i].partition('=')
+                env[k] = v
+                i += 1
+        variants.append((label, (env, extra)))
     if len(variants) < 2:
         sys.exit(__doc__)
     for rep in range(2):
-        for label, extra in variants:
+        for label, (extra_env, extra_args) in variants:
             env = dict(os.environ)
-            env.update(extra)
-            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--no-fast', '--steps', steps],
+            env.update(extra_env)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline', '--no-fast', '--steps', steps] + extra_args,
                                  capture_output=True, text=True, env=env, cwd=ROOT)
             try:
                 d = json.loads(out.stdout.strip().splitlines()[-1])
