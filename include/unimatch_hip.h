@@ -352,6 +352,10 @@ int um_local_corr_softmax(const float* f0, const float* f1, float* out,
  * flow: [B, 2, h, w]; cost: [B, (2r+1)^2, h, w]. */
 int um_local_corr_with_flow(const float* f0, const float* f1, const float* flow, float* cost,
                             int batch, int h, int w, int channels, int radius, void* stream);
+/* The same with the reference's `dilation` argument (matching.py:86-91): taps at p + dilation * d_k + flow(p).  dilation = 1 is
+ * um_local_corr_with_flow; larger dilations take a plain four-corner gather per tap (no caller of the reference uses them). */
+int um_local_corr_with_flow_dilated(const float* f0, const float* f1, const float* flow, float* cost,
+                                    int batch, int h, int w, int channels, int radius, int dilation, void* stream);
 /* Same cost volume written channels-last as the operand planes of the motion encoder's 1x1 convolution
  * (unimatch/reg_refine.py:11,20): planes_out [2][plane_rows][ld], pixel row = (2r+1)^2 taps then zeros up to ld; the fp32
  * [B, taps, h, w] volume is never formed ("K4 fused into convc1"). */

@@ -256,6 +256,21 @@ def local_corr_softmax(feature0, feature1, radius, one_d=False):
     return flow
 
 
+def local_corr_with_flow_dilated(feature0, feature1, flow, radius, dilation):
+    """matching.py:86-123 with its ``dilation`` argument, in the reference's own form: one bilinear sample (zeros padding,
+    align_corners) per tap at ``p + dilation * d_k + flow(p)``; taps dy-outer / dx-inner."""
+    b, c, h, w = feature0.shape
+    grid = pixel_grid(h, w, feature0.dtype)
+    out = []
+    for dy in range(-radius, radius + 1):
+        for dx in range(-radius, radius + 1):
+            pos = grid[None] + flow + torch.tensor([dx * dilation, dy * dilation], dtype=feature0.dtype).view(1, 2, 1, 1)
+            norm = torch.stack([2 * pos[:, 0] / (w - 1) - 1, 2 * pos[:, 1] / (h - 1) - 1], -1)
+            samp = torch.nn.functional.grid_sample(feature1, norm, mode='bilinear', padding_mode='zeros', align_corners=True)
+            out.append((feature0 * samp).sum(1) / c ** 0.5)
+    return torch.stack(out, 1)
+
+
 def local_corr_with_flow(feature0, feature1, flow, radius):
     """matching.py:86-123: ``out[k,p] = f0(p) . bilinear(f1, p + d_k + flow(p)) / sqrt(C)``, zeros outside.
 

@@ -1373,3 +1373,15 @@ def test_hip_graph_replay_of_the_depth_path():
             got = graphed(i0.to(DEV), i1.to(DEV), **kw)['flow_preds'][0]
             assert torch.equal(got, want), (name, seed)
         assert all(v is not False for v in graphed._graphs.values()), name
+
+
+@pytest.mark.parametrize('dilation', [1, 2, 3])
+def test_cost_volume_dilation(ops, dilation):
+    """The reference's `dilation` argument of local_correlation_with_flow (matching.py:86-91; 1 in all of its callers): um_local_corr_with_flow_dilated
+    against the reference's own gather form in fp64, incl. taps that leave the image."""
+    b, h, w = 2, 20, 28
+    f0, f1 = rnd(1200, b, C, h, w), rnd(1201, b, C, h, w)
+    flow = rnd(1202, b, 2, h, w, scale=3.0)
+    want = hp.local_corr_with_flow_dilated(f0.double(), f1.double(), flow.double(), 4, dilation)
+    got = ops.local_corr_with_flow(tok(f0).to(DEV), tok(f1).to(DEV), flow.to(DEV), h, w, 4, dilation=dilation)
+    assert got.shape == want.shape and err(got, want)[1] < 3e-6 * max(1.0, want.abs().max().item())

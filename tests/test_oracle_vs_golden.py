@@ -164,3 +164,24 @@ def test_end_to_end_bidirectional(golden):
     out = oracle_e2e('gmdepth_s1', extra=dict(pred_bidir_depth=True))
     assert out.shape == g['gmdepth_s1_bidir.fp32'].shape
     assert (out - g['gmdepth_s1_bidir.fp32']).abs().mean().item() < 1e-4
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir('/root/reference/unimatch'), reason='needs the reference checkout (build container only)')
+@pytest.mark.parametrize('dilation', [1, 2, 3])
+def test_cost_volume_dilation_against_the_reference(dilation):
+    """The oracle's dilated cost volume (the checker of um_local_corr_with_flow_dilated) against the real
+    local_correlation_with_flow(..., dilation=d) (matching.py:86-123) -- no fixture exists for dilation != 1 because no caller of
+    the reference uses it; this pins the restatement where the reference is present."""
+    import sys
+    sys.path.insert(0, '/root/reference')
+    try:
+        from unimatch.matching import local_correlation_with_flow as ref
+    finally:
+        sys.path.remove('/root/reference')
+    g = torch.Generator().manual_seed(7)
+    f0, f1 = torch.randn(2, 128, 12, 16, generator=g), torch.randn(2, 128, 12, 16, generator=g)
+    flow = torch.randn(2, 2, 12, 16, generator=g) * 3
+    want = ref(f0, f1, flow, 4, dilation=dilation)
+    assert maxdiff(hp.local_corr_with_flow_dilated(f0, f1, flow, 4, dilation), want) < 2e-5
+    if dilation == 1:
+        assert maxdiff(hp.local_corr_with_flow(f0, f1, flow, 4), want) < 2e-5

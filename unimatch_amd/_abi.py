@@ -77,6 +77,7 @@ SIGNATURES = {
     'um_prop_global_attn_planes': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_local_corr_softmax': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
     'um_local_corr_with_flow': (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    'um_local_corr_with_flow_dilated': (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     'um_local_corr_feat_planes_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'um_local_corr_feat_planes': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
     'um_local_corr_with_flow_feat_supported': (_c_int, [_c_int] * 4),

@@ -556,6 +556,72 @@ extern "C" int um_local_corr_with_flow_planes(const float* f0, const float* f1, 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// local_correlation_with_flow with a tap DILATION (unimatch/matching.py:86-123, `dilation` argument; the reference's callers
+// all pass 1, which the kernels above serve): taps at p + dilation * d_k + flow(p).  With dilation > 1 the taps of a pixel no
+// longer share their bilinear corners, so every tap is sampled for itself (4 corner dots); wave per pixel, lanes = 16 tap
+// slots x 4 channel quarters as everywhere in this file.  A correctness path for the reference's full signature, not a hot one.
+__global__ __launch_bounds__(256) void local_corr_with_flow_dilated_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                                           const float* __restrict__ flow, float* __restrict__ cost,
+                                                                           int batch, int h, int w, int radius, int dilation) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w, k = 2 * radius + 1, taps = k * k;
+    const long total = (long)batch * L;
+    const int rounds = (taps + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
+        const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+        const int y = p / w, x = p - y * w;
+        const float px = (float)x + flow[((long)b * 2) * L + p], py = (float)y + flow[((long)b * 2 + 1) * L + p];
+        f32x4 a[8];
+        load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
+        for (int r = 0; r < rounds; ++r) {
+            const int t = r * 16 + slot;
+            const bool tap = t < taps;
+            const int dy = (tap ? t : 0) / k - radius, dx = (tap ? t : 0) % k - radius;
+            const float sx = px + (float)(dx * dilation), sy = py + (float)(dy * dilation);
+            const float fx0 = floorf(sx), fy0 = floorf(sy);
+            const float wx = sx - fx0, wy = sy - fy0;
+            const int x0 = (int)fminf(fmaxf(fx0, -1.0e6f), 1.0e6f), y0 = (int)fminf(fmaxf(fy0, -1.0e6f), 1.0e6f);
+            float d = 0.f;
+            if (tap) {
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const int yy = y0 + cy, xx = x0 + cx;
+                        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                            const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
+                            d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
+                        }
+                    }
+            }
+            d = quad_sum(d);
+            if (tap && quarter == 0) cost[((long)b * taps + t) * L + p] = d * scale;
+        }
+    }
+}
+
+extern "C" int um_local_corr_with_flow_dilated(const float* f0, const float* f1, const float* flow, float* cost, int batch, int h, int w,
+                                               int channels, int radius, int dilation, void* stream) {
+    if (dilation == 1) return um_local_corr_with_flow(f0, f1, flow, cost, batch, h, w, channels, radius, stream);
+    if (int e = local_check(f0, f1, cost, batch, h, w, channels)) return e;
+    if (!flow || dilation < 1) {
+        um_set_error("um_local_corr_with_flow_dilated: null flow or dilation=%d < 1", dilation);
+        return -1;
+    }
+    if (radius < 1 || (2 * radius + 1) * (2 * radius + 1) > K4_MAX_TAPS) {
+        um_set_error("radius=%d unsupported (at most %d taps)", radius, K4_MAX_TAPS);
+        return -4;
+    }
+    ScopedKernelTimer timer(UM_K_COST_VOLUME, (hipStream_t)stream);
+    um_census_hit(UM_V_K4_VALU);
+    hipLaunchKernelGGL(local_corr_with_flow_dilated_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0, (hipStream_t)stream,
+                       f0, f1, flow, cost, batch, h, w, radius, dilation);
+    return (int)hipGetLastError();
+}
+
 extern "C" int um_prop_local_attn(const float* q, const float* k, const float* value, float* out, int batch, int h,
                                   int w, int channels, int value_channels, int radius, void* stream) {
     if (int e = local_check(q, k, out, batch, h, w, channels)) return e;

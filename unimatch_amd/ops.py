@@ -760,7 +760,9 @@ class HipOps:
         _abi.check(code, 'um_local_corr_softmax')
         return out
 
-    def local_corr_with_flow(self, f0, f1, flow, h, w, radius):
+    def local_corr_with_flow(self, f0, f1, flow, h, w, radius, dilation=1):
+        """``local_correlation_with_flow`` (matching.py:86-123) -> ``[B, (2r+1)^2, h, w]``; ``dilation`` as in the reference
+        (1 everywhere in its callers; other values take ``um_local_corr_with_flow_dilated``'s plain gather)."""
         b, l, c = f0.shape
         _check_tokens('f0', f0, tokens=h * w)
         _check_tokens('f1', f1, b, l)
@@ -770,6 +772,11 @@ class HipOps:
         k = 2 * radius + 1
         out = torch.empty((b, k * k, h, w), dtype=torch.float32, device=f0.device)
         meta = {'flops': 2.0 * b * l * (k + 1) ** 2 * c, 'bytes': 2.0 * 4 * b * l * c + 8.0 * b * l + 4.0 * k * k * b * l}
+        if dilation != 1:
+            code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_dilated(
+                _ptr(f0), _ptr(f1), _ptr(flow.contiguous()), _ptr(out), b, h, w, c, radius, int(dilation), _stream()), meta)
+            _abi.check(code, 'um_local_corr_with_flow_dilated')
+            return out
         feat = self._k4_feat_planes(f0, f1, h, w, radius)
         if feat is not None:
             code = self._launch('local_corr_with_flow', lambda: self.lib.um_local_corr_with_flow_feat(
