@@ -68,6 +68,37 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, q):
+    """make_gather on a box without GPU / RCCL: the library communicator cannot be built on any rank, every rank must learn that
+    through the SAME collectives (broadcast of rank 0's outcome, MIN all-reduce of the agreement flag) and fall back together."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from unimatch_amd.dist import TorchGather, make_gather
+        gather, kind = make_gather(rank, world, torch.device('cpu'))
+        ok = isinstance(gather, TorchGather) and 'torch.distributed' in kind
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)                                   # the group is still in step after the fallback
+        q.put((rank, ok, t.item() == 3.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='exercises the no-GPU fallback agreement')
+def test_gather_bootstrap_falls_back_on_every_rank_together():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1] and all(r[1] and r[2] for r in results), results
+
+
 def test_world_size_two_gloo():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
