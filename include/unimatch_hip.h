@@ -53,7 +53,14 @@ extern "C" {
 int um_version(void);
 const char* um_last_error_string(void);
 
-/* Optional measurement aid: when enabled, every launch of the kernels below is bracketed by a pair of
+/* =============================================================================================
+ * MEASUREMENT ABI (um_timing_*, um_census_*): not part of the reference's operator interface.  It exists so that bench.py and
+ * the parity tests can (a) time individual kernels with hipEvents on the stream they are launched on and (b) assert which
+ * kernel instantiation served a call.  Both are OFF by default; while off the library keeps no state at all and every
+ * entry point below is a pure function of its arguments.  Micro-benchmarks of the hardware itself (um_debug_*) are NOT in
+ * the shipped library: they live in diagnostic builds only (end of this header).
+ * =============================================================================================
+ * Kernel timing: when enabled, every launch of the kernels below is bracketed by a pair of
  * hipEvents recorded on the launch stream itself; um_timing_collect() waits for them, returns the summed
  * kernel time and launch count since the last collect, and recycles the events.  Off by default (then the
  * library keeps no state at all).  Two event records per launch are not free (~6 % of a 14 ms forward with every
@@ -90,20 +97,9 @@ const char* um_last_error_string(void);
 #define UM_V_COUNT 13
 int um_census_enable(int on);
 long um_census_count(int variant);
-
-/* Diagnostic: a memory-free loop of independent 32x32x16 fp16 MFMAs on every CU (8 * iters MFMAs per wave, 1024 workgroups of
- * 8 waves): the sustained matrix-pipe rate of this part under its power limit, with one constant operand value or with
- * pseudo-random operands (data toggling costs clock).  sink: any device float. */
-int um_debug_mfma_peak(float* sink, int iters, int random_operands, void* stream);
-/* Diagnostic: the same loop with s_memtime stamps -- 256 workgroups of `waves` (4 | 8) waves, 8 * iters MFMAs per wave, on one accumulator
- * (`chain`) or four; ticks[256 * waves] receives every wave's elapsed s_memtime ticks.  With the host's wall time of the launch this
- * calibrates the tick rate and the ticks per MFMA the attention kernel's section stamps are read against (tools/mfma_ticks.py). */
-int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int iters, int random_operands, int waves, int chain, void* stream);
-/* Diagnostic: the attention kernel's QK^T pattern alone -- 256 workgroups of 4 waves, per "tile" 16 ds_read_b128 two k-steps ahead of the 24
- * MFMAs they feed (mode 0), or the same stream with the MFMAs on loop-invariant A registers (mode 1); ticks[1024]. */
-int um_debug_mfma_lds(unsigned long long* ticks, float* sink, int tiles, int mode, void* stream);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
+/* ===================================== end of the measurement ABI ============================= */
 
 /* ---------------------------------------------------------------------------------------------
  * Windowed single-head attention  softmax(q k^T / sqrt(C) + shift_mask) v   inside windows.
@@ -497,6 +493,25 @@ size_t um_workspace_bytes_local_corr_with_flow(int batch, int h, int w, int chan
 size_t um_workspace_bytes_prop_local_attn(int batch, int h, int w, int channels, int mode);
 size_t um_workspace_bytes_depth_corr_softmax(int batch, int h, int w, int channels, int mode);
 size_t um_workspace_bytes_allgather_preds(int batch, int h, int w, int channels, int mode);
+
+/* =============================================================================================
+ * DIAGNOSTIC BUILDS ONLY (`python -m unimatch_amd.build --variant diag` -> unimatch_amd/_variants/libdiag.so, loaded through
+ * UM_LIB): hardware micro-benchmarks behind -DUM_DIAGNOSTIC_BUILD (csrc/microbench.hip).  The shipped libunimatch_hip.so
+ * exports NO um_debug_* symbol (tests/test_host_logic_cpu.py::test_library_exports_every_declared_symbol).
+ * ============================================================================================= */
+#ifdef UM_DIAGNOSTIC_BUILD
+/* Diagnostic: a memory-free loop of independent 32x32x16 fp16 MFMAs on every CU (8 * iters MFMAs per wave, 1024 workgroups of
+ * 8 waves): the sustained matrix-pipe rate of this part under its power limit, with one constant operand value or with
+ * pseudo-random operands (data toggling costs clock).  sink: any device float. */
+int um_debug_mfma_peak(float* sink, int iters, int random_operands, void* stream);
+/* Diagnostic: the same loop with s_memtime stamps -- 256 workgroups of `waves` (4 | 8) waves, 8 * iters MFMAs per wave, on one accumulator
+ * (`chain`) or four; ticks[256 * waves] receives every wave's elapsed s_memtime ticks.  With the host's wall time of the launch this
+ * calibrates the tick rate and the ticks per MFMA the attention kernel's section stamps are read against (tools/mfma_ticks.py). */
+int um_debug_mfma_ticks(unsigned long long* ticks, float* sink, int iters, int random_operands, int waves, int chain, void* stream);
+/* Diagnostic: the attention kernel's QK^T pattern alone -- 256 workgroups of 4 waves, per "tile" 16 ds_read_b128 two k-steps ahead of the 24
+ * MFMAs they feed (mode 0), or the same stream with the MFMAs on loop-invariant A registers (mode 1); ticks[1024]. */
+int um_debug_mfma_lds(unsigned long long* ticks, float* sink, int tiles, int mode, void* stream);
+#endif /* UM_DIAGNOSTIC_BUILD */
 
 #ifdef __cplusplus
 }

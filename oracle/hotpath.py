@@ -174,13 +174,27 @@ def transformer_layer(source, target, p, prefix, h, w, geom, with_ffn):
     return source + msg
 
 
-def feature_transformer(feature0, feature1, p, attn_type, splits, num_layers=6, prefix=''):
-    """FeatureTransformer.forward (transformer.py:226-294).  Returns updated (feature0, feature1)."""
+def transformer_block(a, bt, p, i, attn_type, splits, h, w, prefix=''):
+    """Block ``i`` of the stack on the stream ``a = [f0; f1]`` (tokens) with cross-attention target ``bt = [f1; f0]`` as it was
+    BEFORE the block (transformer.py:271-291) -> the updated stream."""
+    with_shift = ('swin' in attn_type) and splits > 1 and i % 2 == 1
+    g_self = attention_geometry(attn_type, True, splits, h, w, with_shift)
+    g_cross = attention_geometry(attn_type, False, splits, h, w, with_shift)
+    lp = f'{prefix}layers.{i}.'
+    a = transformer_layer(a, a, p, lp + 'self_attn.', h, w, g_self, with_ffn=False)
+    return transformer_layer(a, bt, p, lp + 'cross_attn_ffn.', h, w, g_cross, with_ffn=True)
+
+
+def feature_transformer(feature0, feature1, p, attn_type, splits, num_layers=6, prefix='', taps=None, tag=''):
+    """FeatureTransformer.forward (transformer.py:226-294).  Returns updated (feature0, feature1).
+    ``taps`` (dict): receives the token stream ``[f0; f1]`` entering the stack (``xin{tag}``) and leaving block i (``blk{i}{tag}``)."""
     b, c, h, w = feature0.shape
     t0 = feature0.flatten(2).transpose(1, 2)
     t1 = feature1.flatten(2).transpose(1, 2)
     a = torch.cat([t0, t1], 0)            # stream being updated
     bt = torch.cat([t1, t0], 0)           # its cross-attention target
+    if taps is not None:
+        taps[f'xin{tag}'] = a
     for i in range(num_layers):
         with_shift = ('swin' in attn_type) and splits > 1 and i % 2 == 1
         g_self = attention_geometry(attn_type, True, splits, h, w, with_shift)
@@ -189,6 +203,8 @@ def feature_transformer(feature0, feature1, p, attn_type, splits, num_layers=6, 
         a = transformer_layer(a, a, p, lp + 'self_attn.', h, w, g_self, with_ffn=False)
         a = transformer_layer(a, bt, p, lp + 'cross_attn_ffn.', h, w, g_cross, with_ffn=True)
         bt = torch.cat([a[b:], a[:b]], 0)
+        if taps is not None:
+            taps[f'blk{i}{tag}'] = a
     f0 = a[:b].transpose(1, 2).reshape(b, c, h, w)
     f1 = a[b:].transpose(1, 2).reshape(b, c, h, w)
     return f0, f1

@@ -152,11 +152,13 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
         if flow is not None:
             disp = torch.cat([-flow, torch.zeros_like(flow)], 1) if task == 'stereo' else flow
             f1 = warp(f1, disp)
+            if taps is not None:
+                taps[f'flow_up_s{s}'], taps[f'f1_warp_s{s}'] = flow, f1
         splits = attn_splits_list[s]
         prop_r = prop_radius_list[s]
         f0, f1 = hp.add_position(f0, f1, splits)
         tp = {k[len('transformer.'):]: v for k, v in p.items() if k.startswith('transformer.')}
-        f0, f1 = hp.feature_transformer(f0, f1, tp, attn_type, splits, num_transformer_layers)
+        f0, f1 = hp.feature_transformer(f0, f1, tp, attn_type, splits, num_transformer_layers, taps=taps, tag=f'_s{s}')
         if taps is not None:
             taps[f'f0_s{s}'], taps[f'f1_s{s}'] = f0, f1
         if task == 'depth':
@@ -209,6 +211,8 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
             proj = F.conv2d(f0, p['refine_proj.weight'], p['refine_proj.bias'])
             net, inp = torch.tanh(proj[:, :128]), torch.relu(proj[:, 128:])
             net, mask, delta = update_block(net, inp, corr, flow, p)
+            if taps is not None and it == num_reg_refine - 1 and mask is not None:
+                taps['mask_last'] = mask
             if task == 'depth':
                 flow = (flow - delta).clamp(min=min_depth, max=max_depth)
             else:
@@ -224,6 +228,8 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
                         min=min_depth, max=max_depth)[:, :1]
                 else:
                     pred = convex_upsample(flow, mask, upsample_factor)
+    if taps is not None:
+        taps['pred_raw'] = pred
     if task == 'stereo':
         pred = pred.squeeze(1)
     if task == 'depth':

@@ -5,6 +5,7 @@ import ctypes
 import inspect
 import os
 import re
+import subprocess
 import sys
 
 import pytest
@@ -157,9 +158,12 @@ def test_position_tokens_bit_exact(golden):
 
 
 # ------------------------------------------------------------------ the C-ABI library
-def declared_symbols():
+def declared_symbols(diagnostic=False):
+    """Entry points the header declares for the shipped library (or, with ``diagnostic``, inside #ifdef UM_DIAGNOSTIC_BUILD)."""
     text = open(os.path.join(ROOT, 'include', 'unimatch_hip.h')).read()
-    return sorted(set(re.findall(r'\b(um_[a-z0-9_]+)\s*\(', text)))
+    head, _, rest = text.partition('#ifdef UM_DIAGNOSTIC_BUILD')
+    diag, _, tail = rest.partition('#endif /* UM_DIAGNOSTIC_BUILD */')
+    return sorted(set(re.findall(r'\b(um_[a-z0-9_]+)\s*\(', diag if diagnostic else head + tail)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -171,6 +175,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_abi.SIGNATURES) == names                     # the ctypes table mirrors the header
     assert _abi.load().um_version() == 200
+    # harness / product separation: hardware micro-benchmarks exist in diagnostic builds only
+    assert not any(n.startswith('um_debug_') for n in names)
+    assert sorted(_abi.DIAG_SIGNATURES) == declared_symbols(diagnostic=True)
+    exported = subprocess.run(['nm', '-D', '--defined-only', _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'um_debug_' not in exported, [ln for ln in exported.splitlines() if 'um_debug_' in ln]
 
 
 def test_abi_argument_errors_without_gpu():

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from unimatch_amd import _abi  # noqa: E402
 
-lib = _abi.load()
+lib = _abi.load_diagnostic()      # um_debug_*: `python -m unimatch_amd.build --variant diag`, UM_LIB=unimatch_amd/_variants/libdiag.so
 sink = torch.zeros(1, device='cuda')
 stream = torch.cuda.current_stream().cuda_stream
 iters = 40000

@@ -22,9 +22,6 @@ _c_int, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 SIGNATURES = {
     'um_version': (_c_int, []),
     'um_last_error_string': (ctypes.c_char_p, []),
-    'um_debug_mfma_peak': (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p]),
-    'um_debug_mfma_lds': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    'um_debug_mfma_ticks': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     'um_timing_enable': (_c_int, [_c_int]),
     'um_timing_collect': (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
     'um_window_attn_workspace_bytes': (_c_size_t, [_c_int] * 4),
@@ -102,6 +99,12 @@ SIGNATURES = {
     'um_allgather_preds': (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 COMM_ID_BYTES = 128
+# hardware micro-benchmarks: exported by diagnostic builds only (`python -m unimatch_amd.build --variant diag`, UM_LIB=...)
+DIAG_SIGNATURES = {
+    'um_debug_mfma_peak': (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p]),
+    'um_debug_mfma_lds': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    'um_debug_mfma_ticks': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+}
 
 _lib = None
 
@@ -130,7 +133,21 @@ def load():
             raise HipExtensionError(f'{LIB_PATH} does not export {name}') from exc
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():        # present in diagnostic builds only
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_diagnostic():
+    """The library with the um_debug_* micro-benchmarks: a diagnostic build loaded through UM_LIB."""
+    lib = load()
+    if not hasattr(lib, 'um_debug_mfma_peak'):
+        raise HipExtensionError('the shipped library carries no um_debug_* symbol: build a diagnostic variant '
+                                '(`python -m unimatch_amd.build --variant diag`) and set UM_LIB=unimatch_amd/_variants/libdiag.so')
     return lib
 
 

@@ -11,8 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libunimatch_hip.so')
-SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip', 'microbench.hip',
+SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip',
            'rccl_gather.hip', 'local_corr_mfma.hip', 'aliases.hip']
+# hardware micro-benchmarks (um_debug_*): diagnostic builds only, never in the shipped library
+DIAG_SOURCES = ['microbench.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
 # per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
 EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize'], 'window_attn.hip': ['-fno-slp-vectorize'],
@@ -65,7 +67,8 @@ def build_variant(name, defines, verbose=False):
     objdir = os.path.join(HERE, '_variants', '_obj_' + name)
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    for src in SOURCES:
+    defines = list(defines) + ['-DUM_DIAGNOSTIC_BUILD']
+    for src in SOURCES + DIAG_SOURCES:
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + ['-c', os.path.join(CSRC, src), '-o', o]
         if verbose:
