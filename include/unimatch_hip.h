@@ -453,6 +453,9 @@ int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long p
  *                       others poll for it up to timeout_seconds (< 0: forever).  The caller chooses a job-unique path; rank 0
  *                       removes a leftover at `path` first, the record carries the world size and a wall-clock stamp (records
  *                       older than 10 minutes are ignored) and rank 0 deletes it once every rank has joined.
+ *   um_comm_init_file_nonce  the same with a caller-chosen per-job nonce stored in the record: readers skip records of another
+ *                       nonce, so a job relaunched under the same path right after a crash (leftover record still fresh) never
+ *                       joins the dead id.  um_comm_init_file is nonce 0 on both sides.
  *   um_allgather_preds  ncclAllGather(send, recv, count_per_rank floats) enqueued on `stream` (the caller's compute or side
  *                       stream; no host synchronisation).  recv: [world][count_per_rank], rank major.
  *   um_comm_world       number of ranks of the communicator (ncclCommCount);  um_comm_destroy releases it.
@@ -463,6 +466,7 @@ int um_instance_norm_fwd(const float* x, const float* shortcut, float* y, long p
 int um_comm_unique_id(void* id_out /* UM_COMM_ID_BYTES, host */);
 int um_comm_init_rank(void** comm_out, const void* id /* UM_COMM_ID_BYTES, host */, int rank, int world);
 int um_comm_init_file(void** comm_out, const char* path, int rank, int world, int timeout_seconds);
+int um_comm_init_file_nonce(void** comm_out, const char* path, int rank, int world, int timeout_seconds, int nonce);
 int um_comm_world(void* comm);
 int um_comm_destroy(void* comm);
 int um_allgather_preds(void* comm, const float* send, float* recv, size_t count_per_rank, void* stream);

@@ -84,6 +84,79 @@ def _gather_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _rank0_failure_worker(rank, world, port, q):
+    """Past the preflight (device context patched out), um_comm_unique_id fails on RANK 0 ONLY: the error must reach rank 1 through
+    the bootstrap's broadcast (rank 1 must not sit in it alone), both ranks must agree and fall back together, with a warning."""
+    import contextlib
+    import warnings
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from unimatch_amd import _abi
+        from unimatch_amd import dist as umd
+        torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()          # this process only: let the bootstrap reach RCCL
+        lib = _abi.load()
+        calls = {'uid': 0, 'init': 0}
+
+        class Patched:
+            def __getattr__(self, name):
+                if name == 'um_comm_unique_id':
+                    def fail(_buf):
+                        calls['uid'] += 1
+                        return -5                                                # UM_ERR_COLLECTIVE
+                    return fail
+                if name == 'um_comm_init_rank':
+                    def init(*_a):
+                        calls['init'] += 1
+                        return -5
+                    return init
+                return getattr(lib, name)
+        _abi._lib = Patched()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            gather, kind = umd.make_gather(rank, world, torch.device('cpu'))
+        ok = isinstance(gather, umd.TorchGather) and 'unavailable' in kind and any('falls back' in str(w.message) for w in caught)
+        ok = ok and calls['uid'] == (1 if rank == 0 else 0) and calls['init'] == 0      # nobody tried to join a communicator
+        if rank == 1:
+            ok = ok and 'rank 0 could not create' in kind                        # the reason travelled through the broadcast
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)                                                       # the group is still in step
+        q.put((rank, ok, t.item() == 3.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_only_bootstrap_failure_reaches_every_rank():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank0_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1] and all(r[1] and r[2] for r in results), results
+
+
+def test_id_file_readers_skip_records_of_another_job(tmp_path):
+    """A record a crashed job left at the path (right magic, right world, fresh stamp) carries that job's nonce: a reader of
+    another job must NOT take it -- it times out with a message naming its own nonce instead of joining a dead id."""
+    import ctypes
+    import struct
+    import time
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    path = tmp_path / 'id'
+    path.write_bytes(b'UMRCCL02' + struct.pack('<iiq', 2, 1234, int(time.time())) + bytes(128))
+    comm = ctypes.c_void_p()
+    t0 = time.time()
+    rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321)
+    assert rc == -5 and b'nonce 4321' in lib.um_last_error_string() and time.time() - t0 < 10
+    assert path.exists()                                    # a reader never removes the record
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='exercises the no-GPU fallback agreement')
 def test_gather_bootstrap_falls_back_on_every_rank_together():
     ctx = mp.get_context('spawn')

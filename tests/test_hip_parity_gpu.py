@@ -1267,9 +1267,76 @@ def test_split_handoffs_repeat_under_uneven_load():
     lib.um_census_enable(0)
     assert census['ffn_hsplit'] == launches >= 200 and census['ffn_tile'] == 0, census
     torch.cuda.synchronize()
-    for name in ('_ks_ws', '_ffn_ws'):
-        for buf in getattr(o, name).values():
-            assert int(buf[:64].count_nonzero()) == 0, name                  # the flags every launch must leave zero (>= 16 of them)
+    assert {k[0] for k in o._split_ws} == {'_ks_ws', '_ffn_ws'}
+    for key, buf in o._split_ws.items():
+        assert int(buf[:64].count_nonzero()) == 0, key                       # the flags every launch must leave zero (>= 16 of them)
+
+
+def _graph_case(name, hh, ww, batch=1):
+    ck, fk = CONFIGS[name]
+    model = UniMatch(**ck).eval()
+    model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}))
+    model = model.to(DEV)
+    i0, i1 = synth_images(batch, hh, ww, seed=11, kind='shift')
+    return model, i0.to(DEV), i1.to(DEV), fk
+
+
+def test_graph_capture_owns_its_split_workspaces():
+    """the split workspaces (arrival counters) of a captured forward are allocated and zeroed by the eager
+    warm-up, never inside the capture; every graph owns its own buffers (two graphs share no counter) and the eager path keeps
+    its per-stream ones; a first-time request inside a capture is refused instead of baking in a pool buffer."""
+    from unimatch_amd.graph import GraphedUniMatch
+    model, i0, i1, fk = _graph_case('gmflow_s1', 320, 448)        # config 1's size: key-split attention, hidden-split FFN
+    eager = model(i0, i1, **fk)['flow_preds'][0]
+    ops = model.ops
+    eager_keys = set(ops._split_ws)
+    assert eager_keys and all(isinstance(k[2], int) for k in eager_keys)     # keyed by stream
+    g1, g2 = GraphedUniMatch(model), GraphedUniMatch(model)
+    a = g1(i0, i1, **fk)['flow_preds'][0]
+    b = g2(i0, i1, **fk)['flow_preds'][0]
+    assert torch.equal(a, eager) and torch.equal(b, eager)
+    assert set(ops._split_ws) == eager_keys and ops.workspace_owner is None  # nothing of the graphs is left in the shared cache
+    w1, w2 = (next(iter(g._graphs.values()))['workspaces'] for g in (g1, g2))
+    assert w1 and w2 and {k[0] for k in w1} == {k[0] for k in eager_keys}
+    ptrs = [t.data_ptr() for ws in (w1, w2, ops._split_ws) for t in ws.values()]
+    assert len(set(ptrs)) == len(ptrs)                                       # every graph and the eager path: separate counters
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()                        # replayed concurrently on two streams, repeatedly
+    for _ in range(20):
+        for g, st in ((g1, s1), (g2, s2)):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                next(iter(g._graphs.values()))['graph'].replay()
+    torch.cuda.synchronize()
+    for g in (g1, g2):
+        assert torch.equal(next(iter(g._graphs.values()))['out'], eager)
+    for ws in (w1, w2):
+        for buf in ws.values():
+            assert int(buf[:64].count_nonzero()) == 0
+    fresh = HipOps('exact')                                                  # first-time request inside a capture: refused
+    graph = torch.cuda.CUDAGraph()
+    x = rnd(900, 2240, 128).to(DEV)
+    with pytest.raises(RuntimeError, match='inside a stream capture'):
+        with torch.cuda.graph(graph):
+            fresh._split_workspace('_ffn_ws', 1 << 20, x.device)
+    torch.cuda.synchronize()
+
+
+def test_sharded_model_through_the_rccl_gather_at_world_one():
+    """``ShardedUniMatch`` + HipOps with the gather forced at world size 1: shard -> forward -> ``um_allgather_preds`` (RCCL) ->
+    reassembly must return exactly what the plain model returns (flow, and the bidirectional [forward; backward] layout)."""
+    from unimatch_amd import dist as umd
+    model, i0, i1, fk = _graph_case('gmflow_s1', 64, 96, batch=3)
+    want = model(i0, i1, **fk)['flow_preds'][0]
+    umd._GATHER = None
+    sharded = umd.ShardedUniMatch(model, rank=0, world=1, force_gather=True)
+    got = sharded(i0, i1, **fk)['flow_preds'][0]
+    assert umd.GATHER_KIND and 'um_allgather_preds' in umd.GATHER_KIND, umd.GATHER_KIND
+    assert got.shape == want.shape and torch.equal(got, want)
+    want2 = model(i0, i1, pred_bidir_flow=True, **fk)['flow_preds'][0]
+    got2 = sharded(i0, i1, pred_bidir_flow=True, **fk)['flow_preds'][0]
+    assert got2.shape == want2.shape == (6, 2, 64, 96) and torch.equal(got2, want2)
+    umd._GATHER.close()
+    umd._GATHER = None
 
 
 def test_rccl_allgather_at_world_size_one(tmp_path):

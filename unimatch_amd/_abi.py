@@ -94,6 +94,7 @@ SIGNATURES = {
     'um_comm_unique_id': (_c_int, [_c_void_p]),
     'um_comm_init_rank': (_c_int, [ctypes.POINTER(_c_void_p), _c_void_p, _c_int, _c_int]),
     'um_comm_init_file': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_char_p, _c_int, _c_int, _c_int]),
+    'um_comm_init_file_nonce': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_char_p, _c_int, _c_int, _c_int, _c_int]),
     'um_comm_world': (_c_int, [_c_void_p]),
     'um_comm_destroy': (_c_int, [_c_void_p]),
     'um_allgather_preds': (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -109,20 +109,29 @@ extern "C" int um_comm_init_rank(void** comm_out, const void* id, int rank, int 
 // to `path` (atomic on one filesystem); the other ranks poll for a record with the right magic and world that is younger than
 // UM_ID_FILE_MAX_AGE seconds (a file left behind by a crashed job of another day is ignored instead of handing out a dead id),
 // and rank 0 deletes the file once ncclCommInitRank has returned, i.e. after every rank has joined.  Two jobs must not share a
-// path at the same time: key it by job (unimatch_amd.dist.launch_ranks uses the rendezvous port and the launcher's pid).
+// path at the same time: key it by job (unimatch_amd.dist.job_id_file: rendezvous port + launcher pid).  A job that crashed
+// between publish and unlink leaves a record that is still "fresh" for UM_ID_FILE_MAX_AGE seconds: um_comm_init_file_nonce
+// stores a caller-chosen per-job nonce in the record and its readers skip records of another nonce, so a relaunch under the
+// same path never joins the dead id (um_comm_init_file = nonce 0 on both sides).
 #define UM_ID_FILE_MAX_AGE 600
 namespace {
 struct IdRecord {
     char magic[8];
     int world;
-    int pad;
+    int nonce;                  // per-job tag chosen by the caller (0: um_comm_init_file)
     long long stamp;
     unsigned char id[UM_COMM_ID_BYTES];
 };
 const char kIdMagic[8] = {'U', 'M', 'R', 'C', 'C', 'L', '0', '2'};
 }  // namespace
 
+extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int rank, int world, int timeout_seconds, int nonce);
+
 extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, int world, int timeout_seconds) {
+    return um_comm_init_file_nonce(comm_out, path, rank, world, timeout_seconds, 0);
+}
+
+extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int rank, int world, int timeout_seconds, int nonce) {
     if (!comm_out || !path || !*path || world <= 0 || rank < 0 || rank >= world) {
         um_set_error("um_comm_init_file: null pointer / empty path or rank %d outside [0, %d)", rank, world);
         return UM_ERR_BAD_ARG;
@@ -136,6 +145,7 @@ extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, in
         memset(&rec, 0, sizeof(rec));
         memcpy(rec.magic, kIdMagic, sizeof(kIdMagic));
         rec.world = world;
+        rec.nonce = nonce;
         rec.stamp = (long long)time(nullptr);
         if (int e = um_comm_unique_id(rec.id)) return e;
         (void)unlink(path);                                         // a leftover of an earlier job under the same key
@@ -154,11 +164,12 @@ extern "C" int um_comm_init_file(void** comm_out, const char* path, int rank, in
                 const size_t n = fread(&rec, 1, sizeof(rec), f);
                 fclose(f);
                 if (n == sizeof(rec) && memcmp(rec.magic, kIdMagic, sizeof(kIdMagic)) == 0 && rec.world == world &&
-                    (long long)time(nullptr) - rec.stamp <= UM_ID_FILE_MAX_AGE)
+                    rec.nonce == nonce && (long long)time(nullptr) - rec.stamp <= UM_ID_FILE_MAX_AGE)
                     break;
             }
             if (timeout_seconds >= 0 && time(nullptr) - t0 > timeout_seconds) {
-                um_set_error("um_comm_init_file: rank %d waited %d s for a fresh id record at %s", rank, timeout_seconds, path);
+                um_set_error("um_comm_init_file: rank %d waited %d s for a fresh id record of this job (nonce %d) at %s", rank, timeout_seconds,
+                             nonce, path);
                 return UM_ERR_COLLECTIVE;
             }
             usleep(20000);

@@ -13,6 +13,8 @@ import os
 import socket
 import subprocess
 import sys
+import warnings
+import zlib
 
 import torch
 import torch.distributed as dist
@@ -50,7 +52,10 @@ class RcclGather:
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):                       # ncclCommInitRank binds the current device
             if id_file:
-                code = self.lib.um_comm_init_file(ctypes.byref(self.comm), os.fsencode(id_file), rank, world, timeout)
+                # the record carries a per-job nonce (rendezvous port + launcher pid): a record a crashed job left at the same
+                # path within the freshness window is not this job's and is ignored by the readers
+                code = self.lib.um_comm_init_file_nonce(ctypes.byref(self.comm), os.fsencode(id_file), rank, world, timeout,
+                                                        job_nonce())
             else:
                 # Rank 0 ALWAYS broadcasts -- the id, or the reason it could not get one -- so that every rank passes through
                 # the same collective and then raises the same error (a rank-0-only exception in front of the broadcast left
@@ -114,24 +119,57 @@ class TorchGather:
         pass
 
 
+def _agree(ok, world, device):
+    """MIN over the ranks of a local success flag (the launcher's group); identity for a single rank."""
+    if world > 1 and dist.is_initialized():
+        flag = torch.tensor([int(ok)], device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+    return bool(ok)
+
+
+def _preflight(device):
+    """Everything of the RCCL bootstrap that can fail on ONE rank before its first collective: the library loads and the
+    device can be made current."""
+    from . import _abi
+    _abi.load()
+    with torch.cuda.device(torch.device(device)):
+        pass
+
+
 def make_gather(rank, world, device, id_file=None):
     """The data-path collective of a multi-rank job: ``(gather, description)``.  Tries the library's own communicator
-    (``RcclGather``); every rank then agrees -- one MIN all-reduce on the launcher's group -- on whether ALL of them
-    succeeded, and if not all fall back together to ``TorchGather`` (never a mix: mismatched collectives hang)."""
+    (``RcclGather``).  Ranks never end up on mixed collectives (those hang): (1) every rank-local step that can fail before the
+    bootstrap's broadcast is tried first and the ranks agree on it (MIN all-reduce on the launcher's group), so no rank enters
+    the broadcast alone; (2) rank 0 always broadcasts the id or its error; (3) the ranks agree on the outcome and fall back
+    TOGETHER to ``TorchGather``, with a warning.  Without a launcher group (``id_file`` bootstrap, no ``torch.distributed``)
+    there is nothing to agree through: a failure is raised instead of silently diverging."""
     kind = 'um_allgather_preds (ncclAllGather through the C ABI, own communicator)'
-    gather, ok = None, 1
+    can_agree = world == 1 or dist.is_initialized()
+    gather, why = None, None
     try:
-        gather = RcclGather(rank, world, device, id_file=id_file)
+        _preflight(device)
     except Exception as exc:                                        # noqa: BLE001 -- reported in the description
-        kind, ok = f'torch.distributed all_gather_into_tensor (um_comm_init failed: {exc})'[:240], 0
-    if world > 1 and dist.is_initialized():
-        flag = torch.tensor([ok], device=device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and ok:
-            gather.close()
-            gather, ok = None, 0
-            kind = 'torch.distributed all_gather_into_tensor (um_comm_init failed on another rank)'
+        why = f'{type(exc).__name__}: {exc}'
+    if not _agree(why is None, world, device):
+        why = why or 'preflight failed on another rank'
+    else:
+        try:
+            gather = RcclGather(rank, world, device, id_file=id_file)
+        except Exception as exc:                                    # noqa: BLE001
+            why = f'{type(exc).__name__}: {exc}'
+            if not can_agree:
+                raise
+        if not _agree(gather is not None, world, device):
+            if gather is not None:
+                gather.close()
+                gather = None
+            why = why or 'um_comm_init failed on another rank'
     if gather is None:
+        if not can_agree:
+            raise RuntimeError(f'make_gather: no RCCL communicator ({why}) and no torch.distributed group to fall back on')
+        kind = f'torch.distributed all_gather_into_tensor (library communicator unavailable: {why})'[:240]
+        warnings.warn(f'unimatch_amd.dist: rank {rank} falls back to {kind}')
         gather = TorchGather(rank, world, device)
     return gather, kind
 
@@ -142,12 +180,15 @@ _GATHER = None
 def rccl_gather(device=None):
     """The process-wide prediction gather of an initialised multi-rank job on GPUs (created on first use; the library's RCCL
     communicator, or -- agreed by all ranks -- ``torch.distributed`` when that cannot be built)."""
-    global _GATHER
+    global _GATHER, GATHER_KIND
     if _GATHER is None:
-        rank, world = dist.get_rank(), dist.get_world_size()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        _GATHER, _ = make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
+        _GATHER, GATHER_KIND = make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
     return _GATHER
+
+
+GATHER_KIND = None          # description of the collective rccl_gather() settled on (make_gather's second result)
 
 
 def free_port():
@@ -174,10 +215,20 @@ def launch_ranks(script, script_args, nproc, need_gpus=True, env=None):
 
 def job_id_file(port=None):
     """A job-unique path for ``um_comm_init_file`` (rendezvous port + launcher pid), for callers that bootstrap the
-    communicator without ``torch.distributed``."""
+    communicator without ``torch.distributed`` (export it as UM_RCCL_ID_FILE; ``launch_ranks`` itself never needs one: its ranks
+    bootstrap through the launcher's process group)."""
     import tempfile
     port = port if port is not None else os.environ.get('MASTER_PORT', '0')
     return os.path.join(tempfile.gettempdir(), f'um_rccl_id_{port}_{os.getppid()}')
+
+
+def job_nonce():
+    """31-bit tag shared by the ranks of ONE launch (same rendezvous port, same launcher process) and by no other job on the
+    node at the same time: stored in the id-file record, checked by its readers (UM_RCCL_NONCE overrides)."""
+    if os.environ.get('UM_RCCL_NONCE'):
+        return int(os.environ['UM_RCCL_NONCE']) & 0x7fffffff
+    key = f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '0')}:{os.getppid()}"
+    return (zlib.crc32(key.encode()) & 0x7fffffff) or 1
 
 
 def shard_bounds(batch, rank, world):
@@ -195,15 +246,15 @@ def shard_batch(tensor, rank, world):
     return tensor[lo:hi].contiguous()
 
 
-def all_gather_predictions(local, batch, rank, world, parts=1):
-    """Collect per-rank predictions into the full batch on every rank.
+def all_gather_predictions(local, batch, rank, world, parts=1, force=False):
+    """Collect per-rank predictions into the full batch on every rank (``force``: run the collective at world size 1 too).
 
     local: ``[parts * b_r, ...]`` where b_r is this rank's share of ``batch``; ``parts`` = 2 for bidirectional
     outputs, whose layout is [forward(all samples); backward(all samples)] (unimatch.py:139-141) and must be
     rebuilt in that order.  Ranks may own different sample counts: shards are padded to the largest share for
     the collective and trimmed afterwards.
     """
-    if world == 1:
+    if world == 1 and not force:
         return local
     counts = [shard_bounds(batch, r, world)[1] - shard_bounds(batch, r, world)[0] for r in range(world)]
     bmax = max(counts)
@@ -228,16 +279,19 @@ class ShardedUniMatch(torch.nn.Module):
     """Wrap a ``UniMatch`` so that every rank feeds the FULL batch and receives the FULL prediction, while
     computing only its own shard.  With world_size 1 it is the identity wrapper."""
 
-    def __init__(self, model, rank=None, world=None):
+    def __init__(self, model, rank=None, world=None, force_gather=False):
+        """``force_gather``: take the sharded path -- shard, forward, ``um_allgather_preds`` -- even with one rank (the
+        all-gather degenerates to a copy through RCCL): how a 1-GPU box exercises exactly what N ranks run."""
         super().__init__()
         self.model = model
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.force_gather = force_gather
 
     def forward(self, img0, img1, **kw):
         batch = img0.shape[0]
         r, n = self.rank, self.world
-        if n == 1:
+        if n == 1 and not self.force_gather:
             return self.model(img0, img1, **kw)
         if batch < n:
             raise ValueError(f'batch {batch} is smaller than the number of ranks {n}')
@@ -247,4 +301,4 @@ class ShardedUniMatch(torch.nn.Module):
                 kw[key] = shard_batch(kw[key], r, n)
         local = self.model(shard_batch(img0, r, n), shard_batch(img1, r, n), **kw)['flow_preds'][0]
         parts = 2 if (kw.get('pred_bidir_flow') or kw.get('pred_bidir_depth')) else 1
-        return {'flow_preds': [all_gather_predictions(local.contiguous(), batch, r, n, parts)]}
+        return {'flow_preds': [all_gather_predictions(local.contiguous(), batch, r, n, parts, force=self.force_gather)]}

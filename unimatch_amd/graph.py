@@ -30,17 +30,32 @@ class GraphedUniMatch(torch.nn.Module):
     def _capture(self, img0, img1, kw):
         static = {'img0': img0.clone(), 'img1': img1.clone(),
                   'kw': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up: position tables, weight planes, MIOpen solver selection
-            for _ in range(self.warmup):
-                self.model(static['img0'], static['img1'], **static['kw'])
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static['out'] = self.model(static['img0'], static['img1'], **static['kw'])['flow_preds'][0]
-        static['graph'] = graph
+        # The split small-launch workspaces (arrival counters that must be zero between launches) are keyed by an owner token for
+        # the duration of warm-up + capture: the eager warm-up allocates and zeroes them OUTSIDE the capture, the capture bakes
+        # in the same addresses, and this graph then owns them alone (ops.claim_workspaces) -- two graphs replayed concurrently
+        # share no counter, and an aborted capture's buffers are dropped with the token instead of being reused.
+        ops = getattr(self.model, 'ops', None)
+        token = object()
+        if ops is not None and hasattr(ops, 'claim_workspaces'):
+            ops.workspace_owner = token
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up: position tables, weight planes, split workspaces
+                for _ in range(max(1, self.warmup)):
+                    self.model(static['img0'], static['img1'], **static['kw'])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static['out'] = self.model(static['img0'], static['img1'], **static['kw'])['flow_preds'][0]
+            static['graph'] = graph
+            if ops is not None and hasattr(ops, 'claim_workspaces'):
+                static['workspaces'] = ops.claim_workspaces(token)      # alive as long as the graph
+        finally:
+            if ops is not None and hasattr(ops, 'claim_workspaces'):
+                ops.workspace_owner = None
+                ops.claim_workspaces(token)                             # failure path: nobody may reuse what the capture touched
         return static
 
     def forward(self, img0, img1, **kw):

@@ -125,8 +125,10 @@ class HipOps:
         return key, None
 
     def invalidate_weights(self):
-        """Forget every cached operand plane (call after editing weights in place through ``.data``)."""
+        """Forget every cached operand plane (call after editing weights in place through ``.data``) and every split
+        workspace (a launch that was cut short -- aborted capture, device error -- may have left arrival counters non-zero)."""
         self._wcache.clear()
+        self.__dict__.pop('_split_ws', None)
 
     def _cache_put(self, key, tensors, value):
         if len(self._wcache) > 256:
@@ -267,17 +269,35 @@ class HipOps:
         return self._split_workspace('_ks_ws', nbytes, device)
 
     def _split_workspace(self, name, nbytes, device):
-        """Scratch of a split small launch (attention: key split, FFN: hidden split -- partial results + flags): zero at
-        allocation, left zero by every launch; one buffer per kernel, device AND stream (two launches in flight on different
-        streams must not share the flags), grown on demand."""
+        """Scratch of a split small launch (attention: key split, FFN: hidden split -- partial results + arrival counters): zero
+        at allocation, left zero by every launch; one buffer per kernel, device AND owner, grown on demand.  The owner is the
+        current stream (two launches in flight on different streams must not share the counters) -- or, while a
+        ``GraphedUniMatch`` warms up and captures, that graph's token (``workspace_owner``): the buffer is then allocated and
+        zeroed by the eager warm-up OUTSIDE the capture, the capture only bakes its address in, every graph has its own buffer
+        (two graphs replayed concurrently share no counter), and ``claim_workspaces`` hands it to the graph object -- an aborted
+        capture drops it, so a buffer a capture may have left with stale counters is never reused."""
         if not nbytes:
             return None
-        cache = self.__dict__.setdefault(name, {})
-        key = (device, _stream())
+        cache = self.__dict__.setdefault('_split_ws', {})
+        owner = self.workspace_owner if self.workspace_owner is not None else _stream()
+        key = (name, device, owner)
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                # would come from the graph's private pool and only be zeroed by a memset NODE: refuse instead of baking in a
+                # buffer whose counters are garbage if this capture aborts
+                raise RuntimeError(f'{name}: split workspace requested for the first time inside a stream capture; run the '
+                                   'same call eagerly first (GraphedUniMatch warms up under its workspace owner token)')
             buf = cache[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         return buf
+
+    workspace_owner = None     # set by GraphedUniMatch around warm-up + capture (see _split_workspace)
+
+    def claim_workspaces(self, owner):
+        """Remove and return every split workspace allocated under ``owner`` (the graph keeps them alive; nobody else can get them)."""
+        cache = self.__dict__.setdefault('_split_ws', {})
+        mine = {k: cache.pop(k) for k in [k for k in cache if k[2] is owner]}
+        return mine
 
     def window_attention_qproj_merge(self, x, q_weight, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate,
                                      merge_weight, norm, residual=None):
