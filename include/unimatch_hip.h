@@ -421,7 +421,10 @@ int um_flow_warp(const float* feature_tokens, const float* flow, float* out_toke
  *                       (F.interpolate(..., scale_factor=2, mode='bilinear', align_corners=True) * 2: pass mult = 2)
  *   um_depth_cam_pack   cam[B or 2B][30] = Kinv | R | t | K (row major) from intrinsics [B,3,3] with rows 0-1 divided by stride_div
  *                       (unimatch.py:147-150) and pose [B,4,4]; with bidir, entries B..2B-1 carry the inverse pose
- *                       (matching.py:226-233).  Closed-form inverses: no torch.inverse (which synchronises the device)
+ *                       (matching.py:226-233).  Closed-form inverses (adjugate / determinant, evaluated in fp64, rounded once):
+ *                       no torch.inverse (which synchronises the device).  A SINGULAR K or rotation cannot raise as
+ *                       torch.inverse does: its inverse is all NaN, so that sample's predictions are NaN (other samples untouched).
+ *                       Intrinsics / poses held in double by the caller are rounded to fp32 before the call.
  *   um_rigid_flow       flow[B,2,h,w] induced by inv_depth [B,1,h,w] and cam [B][30]: unimatch/geometry.py:99-195 as called
  *                       from the depth refinement (unimatch.py:295-305) */
 int um_flow_upsample2x(const float* flow, float* out, int batch, int channels, int h, int w, float mult, void* stream);

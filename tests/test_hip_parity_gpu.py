@@ -1415,6 +1415,13 @@ def test_per_scale_glue_kernels(ops):
         kk = kd.repeat(2, 1, 1) if bidir else kd
         want = torch.cat([torch.inverse(kk).flatten(1), pd[:, :3, :3].flatten(1), pd[:, :3, 3], kk.flatten(1)], 1)
         assert cam.shape == want.shape and (cam - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    # a singular intrinsics matrix cannot raise from the kernel (torch.inverse would, after a device synchronisation): that sample's
+    # K^-1 is all NaN -- nothing half-finite -- and the other samples are untouched (include/unimatch_hip.h, um_depth_cam_pack)
+    ks = k.clone()
+    ks[1, 1] = ks[1, 0] * 2.0
+    cam_s = ops.depth_cam(ks.to(DEV), pose.to(DEV), 8.0, False).cpu()
+    good = ops.depth_cam(k.to(DEV), pose.to(DEV), 8.0, False).cpu()
+    assert torch.isnan(cam_s[1, :9]).all() and torch.equal(cam_s[0], good[0]) and torch.equal(cam_s[2], good[2])
     inv_depth = (0.2 + rnd(1101, b, 1, h, w).abs()).clamp(0.1, 2.0)
     cam = ops.depth_cam(k.to(DEV), pose.to(DEV), 8.0, False)
     want = om.rigid_flow(1.0 / inv_depth.double().squeeze(1), kd, pose.double())

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         if (tid == 0) *ticket = __hip_atomic_fetch_add(a.hs_flag + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*ticket != (unsigned)(nsplit - 1)) return;             // not the last arriver: done
+        asm volatile("buffer_inv sc1" ::: "memory");               // acquire side of the hand-off, last arriver only (window_attn.hip)
         if (tid == 0) __hip_atomic_store(a.hs_flag + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         if (role == 1) return;
         for (int p = 0; p < nsplit; ++p) {

@@ -218,19 +218,26 @@ extern "C" int um_flow_upsample2x(const float* flow, float* out, int batch, int 
 // (when `bidir`) hold the inverse pose (matching.py:226-233, unimatch.py:296-300).  Inverses in closed form (3x3 adjugate; a pose
 // is affine: [A t; 0 0 0 1]^-1 = [A^-1, -A^-1 t]) instead of torch.inverse, which synchronises the device and keeps the depth
 // path out of HIP graphs.
-__device__ __forceinline__ void inv3(const float* m, float* o) {
-    const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const float id = 1.0f / det;
-    o[0] = c00 * id;
-    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
-    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    o[3] = c01 * id;
-    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
-    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    o[6] = c02 * id;
-    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
-    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+// Adjugate / determinant evaluated in fp64 and rounded once (torch.inverse runs an fp32 LU: this is at least as accurate; inputs
+// given in double are rounded to fp32 by the caller first, as the reference's fp32 tensors are).  A singular matrix cannot raise
+// from a kernel the way torch.inverse does (that would need the device synchronisation this kernel exists to avoid): the
+// inverse is all NaN, so every prediction of that sample is NaN and no other sample is touched (tested).
+__device__ __forceinline__ void inv3(const float* mf, float* o) {
+    double m[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m[j] = (double)mf[j];
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = det != 0.0 ? 1.0 / det : (double)__builtin_nanf("");
+    o[0] = (float)(c00 * id);
+    o[1] = (float)((m[2] * m[7] - m[1] * m[8]) * id);
+    o[2] = (float)((m[1] * m[5] - m[2] * m[4]) * id);
+    o[3] = (float)(c01 * id);
+    o[4] = (float)((m[0] * m[8] - m[2] * m[6]) * id);
+    o[5] = (float)((m[2] * m[3] - m[0] * m[5]) * id);
+    o[6] = (float)(c02 * id);
+    o[7] = (float)((m[1] * m[6] - m[0] * m[7]) * id);
+    o[8] = (float)((m[0] * m[4] - m[1] * m[3]) * id);
 }
 
 __global__ void depth_cam_pack_kernel(const float* __restrict__ intr, const float* __restrict__ pose, float* __restrict__ cam, int batch,

@@ -71,10 +71,9 @@ struct WattnArgs {
     // QPROJ variant: q = x . Wq^T computed in the prologue (transformer.py:58); qp is unused
     const float* x;              // [S][L][128] fp32 source tokens
     const unsigned short* wq;    // planes [NS][128][128] of the query weight, pre-scaled by 2^wshift (stride wm_plane_stride)
-    // KSPLIT instantiation: the first `full` workgroups of the grid serve one query tile each; the others come in groups of `split`
-    // per tile, each on 1 / split of the window's key tiles (small launches: full = 0; big launches: the remainder round)
+    // KSPLIT instantiation (small launches): the workgroups come in groups of `split` per query tile, each on 1 / split of the
+    // window's key tiles
     int split;
-    int full;
     float* ks_part;              // [split tiles][split][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of every part
     unsigned* ks_flag;           // [split tiles] arrival counters, zero between launches
 };
@@ -137,16 +136,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // the others exit.  Nobody spins, so nothing is assumed about residency or dispatch order.
     int wg, wl = 0, part = 0, nsplit = 1;
     if constexpr (KSPLIT) {
-        const int b = blockIdx.x;
-        if (b < a.full) {
-            wg = xcd_remap(b, a.full);                             // (a.full is a multiple of the XCD count or 0)
-        } else {
-            const int j = xcd_remap(b - a.full, (int)gridDim.x - a.full);
-            nsplit = a.split;
-            wl = j / nsplit;                                       // split tile (indexes the slots and the counter)
-            part = j - wl * nsplit;
-            wg = a.full + wl;                                      // query tile of the call
-        }
+        // (a mixed grid -- whole tiles first, key-split remainder behind -- was measured in round 3 and lost; the plan only ever
+        // produces all-split launches, so the kernel no longer carries that path)
+        const int j = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        nsplit = a.split;
+        wl = j / nsplit;                                           // split tile (indexes the slots and the counter)
+        part = j - wl * nsplit;
+        wg = wl;                                                   // query tile of the call
     } else {
         wg = xcd_remap(blockIdx.x, gridDim.x);
     }
@@ -629,6 +625,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (tid == 0) *ticket = __hip_atomic_fetch_add(a.ks_flag + wl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (*ticket != (unsigned)(nsplit - 1)) return;           // not the last arriver: done
+            // Acquire side, last arriver only (one workgroup per tile): invalidate non-local lines at agent scope so that the sc1
+            // loads below cannot hit a copy of a slot this XCD's L2 kept from an EARLIER launch if the parts ever land on
+            // different XCDs (the dispatch-order assumption behind xcd_remap is "speed only").  Unlike an agent-scope RELEASE
+            // this writes nothing back.
+            asm volatile("buffer_inv sc1" ::: "memory");
             __syncthreads();                                         // (the ring is about to take Wm)
             if (tid == 0) __hip_atomic_store(a.ks_flag + wl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
             // merge in part order, starting from part 0's slot (so that the result does not depend on who arrived last)
@@ -820,7 +821,7 @@ static int wattn_key_split(int total, int ntiles) {
 //   * a small launch (total <= slots): every tile key-split `split` ways while the launch fits the chip (batch-1 latency);
 //   * a big launch: one workgroup per tile.
 // Round 3 measured five restructurings of the big launch on the GPU and dropped them all (profiles/r03_attention_experiments.txt;
-// code in git at 85b86af; the kernel still takes `full` > 0): the remainder round of 768 tiles on 512 slots key-split -- as a second launch
+// code in git at 85b86af): the remainder round of 768 tiles on 512 slots key-split -- as a second launch
 // (0.2514 against 0.2403 ms) and, with the ticket hand-off, at the end of the same grid (0.2570 against 0.2473 ms): the half walks
 // pay a second prologue and the hand-off, and the tail they replace is less idle than a round count suggests; 256-query / 8-wave
 // workgroups with a 4-slot K/V ring and the DMA three tiles ahead (equal per-round time); a software-pipelined one-wave-per-SIMD
@@ -1024,7 +1025,6 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     static const float headroom = [] { const char* e = um_debug_env("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
-    a.full = 0;
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (wm && wq) {
         // the layer kernel (query projection + attention + merge + LayerNorm): wattn_plan; without workspace one workgroup per tile
@@ -1038,13 +1038,11 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
                 hipLaunchKernelGGL((window_attn_kernel<Bf16, 1, true, true>), dim3(p.full), dim3(256), 0, stream, a);
             return (int)hipGetLastError();
         }
-        if (p.full > 0) um_census_hit(UM_V_WATTN_TILE);             // whole tiles and key-split tiles share the launch
-        um_census_hit(UM_V_WATTN_KSPLIT);
-        a.full = p.full;
+        um_census_hit(UM_V_WATTN_KSPLIT);                          // (wattn_plan: a launch is all whole tiles or all key-split)
         a.split = p.split;
         a.ks_flag = (unsigned*)ks_ws;
         a.ks_part = (float*)((unsigned char*)ks_ws + align256w((size_t)p.rem * sizeof(unsigned)));
-        const unsigned grid = (unsigned)(p.full + p.rem * p.split);
+        const unsigned grid = (unsigned)(p.rem * p.split);
         if (mode == 0)
             hipLaunchKernelGGL((window_attn_kernel<Fp16, 2, true, true, true>), dim3(grid), dim3(256), 0, stream, a);
         else
