@@ -8,7 +8,10 @@ LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when run as pl
 own N ranks through ``torch.distributed.run``.  It never measures fewer GPUs than asked for: a node with fewer than N
 GPUs, or a launcher whose WORLD_SIZE differs from --gpus, is an error.
 
-Workload (BASELINE.json configs[1]): GMFlow scale-1 optical flow, batch 8 image pairs of 512x768 per GPU, synthetic frames,
+    python bench.py --workload cfg4 --gpus N      BASELINE.json configs[3] as written: GMFlow scale-2 + 6 refinements, GLOBAL batch 32
+                                                  sharded over the N ranks through ShardedUniMatch + um_allgather_preds (strong scaling)
+
+Workload (default; BASELINE.json configs[1]): GMFlow scale-1 optical flow, batch 8 image pairs of 512x768 per GPU, synthetic frames,
 seeded random-init weights.  A "step" is one full forward of the drop-in ``UniMatch`` module (CNN encoder -> 6-block swin
 Transformer -> global correlation softmax -> self-attention propagation -> convex upsampling) with the inputs already
 resident in HBM; with N GPUs every rank runs its own batch (weak scaling, no data-path collective) and the per-rank
@@ -16,14 +19,22 @@ predictions are all-gathered over RCCL (``um_allgather_preds`` of the library's 
 so that the gather of step k overlaps step k+1) -- K timed steps contain K complete all-gathers.
 Rank 0 prints ONE JSON line; ``value`` is whole-job image-pairs/s in EXACT mode (the parity mode).
 
+The headline region is EVENT-FREE (round 4): ``value`` / ``ms_per_step`` come from K steps bracketed by barrier + synchronize with
+no per-kernel event inside.  Directly after it a BREAKDOWN pass runs the same K steps twice with the library's per-kernel hipEvents
+(``um_timing_*``, recorded on the launch stream): once timing only the launches inside the CNN encoder, once only those outside it.
+
 Extra objects on the line:
   roofline              the dominant HIP kernel (windowed attention): algorithmic FLOPs per launch / its mean
-                        launch duration, measured with hipEvents recorded on the launch stream inside the timed region
-                        (two event records per timed launch: the headline is slightly pessimistic), against the dense 16-bit
-                        MFMA peak; ``traffic`` comes from a rocprofv3 PMC pass kept in profiles/ and is nulled when the
-                        kernel source has changed since that pass.  ``frac`` prices attention proper (4 L n C per stream);
-                        the merge Linear and query projection the same launch executes are in ``with_fused_linears``.
+                        launch duration from the breakdown pass, against the dense 16-bit MFMA peak; ``traffic`` / ``mfma_busy``
+                        come from a rocprofv3 PMC pass kept in profiles/ and are nulled when the kernel source has changed
+                        since that pass.  ``frac`` prices attention proper (4 L n C per stream); the merge Linear and query
+                        projection the same launch executes are in ``with_fused_linears``.
   roofline_global_corr  the same for ``gsv4_kernel`` (global correlation / propagation: the kernel the north star names).
+  roofline_ffn          the same for ``ffn_kernel`` (the whole Transformer FFN in one launch, transformer.py:141-144).
+  hot_path_ms_per_step  sum of the kernel durations of everything OUTSIDE the CNN encoder (SURVEY.md 8's path: Transformer,
+                        matching, propagation, upsampling head / refinement), per step, with ``hot_path_kernels`` = the split by
+                        kernel id; ``encoder_ms_per_step`` = the same sum over the encoder's launches (out of
+                        scope, but 45 % of the step); both from the breakdown pass, never from the headline region.
   fast                  the bf16 throughput mode of the same workload (pairs/s, both rooflines, EPE vs fp64): reported beside
                         the headline, never as the headline and never as a parity claim.
   cpu_baseline          the CPU port (oracle/, a torch-CPU restatement of the reference pinned to it by golden fixtures;
@@ -61,7 +72,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--precision', default='exact', choices=['exact', 'fast'],
                     help="headline mode: 'exact' (default, parity mode: fp16 hi+lo split MFMA operands) or 'fast' (bf16)")
-    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4'],
+                    help="cfg2 (default): GMFlow-s1, 8 pairs per GPU, weak scaling.  cfg4: GMFlow-s2 + 6 refinements, GLOBAL batch 32 "
+                         "sharded over the ranks (BASELINE.json configs[3] as written), strong scaling")
+    ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (cfg2, default 8) / global batch (cfg4, default 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
     ap.add_argument('--cpu-iters', type=int, default=8)
@@ -126,46 +140,43 @@ def pmc_mfma_busy(kernel_key, files):
         return None, 'no PMC pass on record for this launch shape'
 
 
-def rooflines(attn, gsv, flops_attn, flops_gsv, precision, batch, flops_attn_fused=0.0):
-    """`achieved` / `frac` price the SURVEY 8(d) figure of the kernel's function alone (attention: 4 L n C per stream); the
-    merge Linear and query projection the attention launch also executes are reported beside it, never inside it."""
-    from unimatch_amd.ops import HipOps
+def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, precision, pmc_ok, bound='mfma'):
+    """One roofline object: `achieved` = algorithmic FLOPs of the kernel's launches in a step / the summed hipEvent
+    duration of those launches (breakdown pass).  With one launch shape per step this is per launch; with several (config 4: two
+    scales) it is the time-weighted aggregate and `avg_launch_ms` the plain mean."""
+    ms, n = timing
+    if not n:
+        return None
     issued = 3.0 if precision == 'exact' else 1.0
-    tag = ('Fp16, 2' if precision == 'exact' else 'Bf16, 1')
-    out = []
-    # the instantiation the bench's attention calls take: key-split remainder round inside the launch or not (um_window_attn_plan)
-    from unimatch_amd import _abi
-    f_, r_, k_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _abi.load().um_window_attn_plan(2 * batch, HEIGHT // 8, WIDTH // 8, HEIGHT // 16, WIDTH // 16, ctypes.byref(f_), ctypes.byref(r_), ctypes.byref(k_))
-    ksplit = 'true' if r_.value > 0 else 'false'
-    for name, key, files, (ms, n), fl in (
-            ('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, {ksplit}>",
-             ['window_attn.hip', 'common.h'], attn, flops_attn),
-            ('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
-             gsv, flops_gsv)):
-        if not n:
-            out.append(None)
-            continue
-        dur = ms / n * 1e-3
-        ach = fl / dur
-        traffic, note = pmc_traffic(key, files) if batch == BATCH else (None, 'non-default batch')
-        busy, busy_note = pmc_mfma_busy(key, files) if batch == BATCH else (None, 'non-default batch')
-        out.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic,
-                    'traffic_unit': 'MB per launch', 'traffic_source': note, 'launches': n,
-                    'avg_launch_ms': round(ms / n, 4), 'algorithmic_gflop_per_launch': round(fl / 1e9, 2),
-                    'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
-                    'mfma_busy': busy, 'mfma_busy_source': busy_note,
-                    'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
-                    'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4)})
-        if name == 'window_attn_kernel' and flops_attn_fused:
-            tot = (fl + flops_attn_fused) / dur
-            out[-1]['with_fused_linears'] = {
-                'note': 'the same launches also execute transformer.py:58 (q projection, prologue) and :137 (merge Linear, '
-                        'epilogue; LayerNorm + residual not counted)',
-                'algorithmic_gflop_per_launch': round((fl + flops_attn_fused) / 1e9, 2), 'achieved': round(tot / 1e12, 2),
-                'frac': round(tot / PEAK_MFMA_16BIT, 4), 'issued_mfma_frac': round(tot * issued / PEAK_MFMA_16BIT, 4)}
-    return out
+    steps = n / launches_per_step
+    dur = ms * 1e-3 / steps                      # seconds of this kernel per step
+    ach = flops_per_step / dur
+    traffic, note = pmc_traffic(key, files) if pmc_ok else (None, 'no PMC pass for this workload / batch')
+    busy, busy_note = pmc_mfma_busy(key, files) if pmc_ok else (None, 'no PMC pass for this workload / batch')
+    return {'kernel': name, 'bound': bound, 'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12,
+            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic,
+            'traffic_unit': 'MB per launch', 'traffic_source': note, 'launches': n,
+            'avg_launch_ms': round(ms / n, 4), 'algorithmic_gflop_per_launch': round(flops_per_step / launches_per_step / 1e9, 2),
+            'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
+            'mfma_busy': busy, 'mfma_busy_source': busy_note,
+            'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
+            'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4),
+            'duration_source': 'hipEvent pairs on the launch stream (um_timing_*), breakdown pass after the event-free headline region'}
+
+
+def cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+KERNEL_NAMES = ['window_attn', 'global_softmax (gsv3/gsv4)', 'split_planes', 'local_corr_softmax', 'cost_volume (K4)', 'prop_local',
+                'depth_corr', 'linear', 'instance_norm / nhwc', 'convex_upsample / warp', 'ffn', 'conv']
 
 
 def main():
@@ -188,6 +199,7 @@ def main():
     distributed = world > 1 or os.environ.get('UM_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    cfg4 = args.workload == 'cfg4'
     gather, gather_kind = None, None
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -195,28 +207,42 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)           # "nccl" is RCCL on ROCm: launcher-side barrier / reductions
-        from unimatch_amd.dist import make_gather
-        gather, gather_kind = make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))   # the data-path collective
+        from unimatch_amd import dist as umd
+        if cfg4:                                                  # ShardedUniMatch gathers through the process-wide collective
+            gather = umd.rccl_gather(dev)
+            gather_kind = umd.GATHER_KIND
+        else:
+            gather, gather_kind = umd.make_gather(rank, world, dev, id_file=os.environ.get('UM_RCCL_ID_FILE'))
 
     from unimatch_amd import UniMatch, _abi
+    from unimatch_amd.dist import ShardedUniMatch, shard_bounds
     from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict
     apply_knobs(args.set)
-    ck, fk = CONFIGS['gmflow_s1']
+    cfg_name = 'gmflow_s2_rr6' if cfg4 else 'gmflow_s1'
+    ck, fk = CONFIGS[cfg_name]
     model = UniMatch(**ck).eval()
     sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()})
     model.load_state_dict(sd)
     model = model.to(dev)
     lib = _abi.load()
 
-    b = args.batch
-    # distinct frames per rank (seeded), resident in HBM before the timed region
-    i0, i1 = synth_images(b, HEIGHT, WIDTH, seed=1000 + rank, kind='shift')
+    if cfg4:
+        gb = args.batch or 32                                     # GLOBAL batch, sharded over the ranks (strong scaling)
+        lo, hi = shard_bounds(gb, rank, world)
+        b = hi - lo                                               # pairs this rank computes
+        i0, i1 = synth_images(gb, HEIGHT, WIDTH, seed=1000, kind='shift')      # every rank holds the full batch, as a caller would
+        runner = ShardedUniMatch(model, rank=rank, world=world, force_gather=distributed)
+    else:
+        b = args.batch or BATCH
+        gb = world * b
+        # distinct frames per rank (seeded), resident in HBM before the timed region
+        i0, i1 = synth_images(b, HEIGHT, WIDTH, seed=1000 + rank, kind='shift')
     i0, i1 = i0.to(dev), i1.to(dev)
-    # The all-gather of step k (25 MB per rank at config 2) runs on a side stream while step k+1 computes: two receive
+    # cfg2: the all-gather of step k (25 MB per rank) runs on a side stream while step k+1 computes: two receive
     # buffers; the compute stream waits for the previous gather before the next one is issued and after the last step
-    # (inside the timed region), so K timed steps contain K complete all-gathers.
-    side = torch.cuda.Stream(device=dev) if distributed else None
-    gathered = [torch.empty(world, b, 2, HEIGHT, WIDTH, device=dev) for _ in range(2)] if distributed else None
+    # (inside the timed region), so K timed steps contain K complete all-gathers.  cfg4: ShardedUniMatch gathers on the compute stream.
+    side = torch.cuda.Stream(device=dev) if distributed and not cfg4 else None
+    gathered = [torch.empty(world, b, 2, HEIGHT, WIDTH, device=dev) for _ in range(2)] if side is not None else None
     pending = {'event': None, 'src': None, 'i': 0}
 
     def finish_gather():
@@ -225,6 +251,8 @@ def main():
             pending['event'] = pending['src'] = None
 
     def step():
+        if cfg4:
+            return runner(i0, i1, **fk)['flow_preds'][0]          # [global batch, 2, H, W] on every rank
         pred = model(i0, i1, **fk)['flow_preds'][0]
         if distributed:
             finish_gather()
@@ -242,14 +270,13 @@ def main():
     step_ms = []
 
     def timed(precision, steps, warmup):
+        """The headline region: K steps, barrier + synchronize on both sides, no per-kernel event inside."""
         model.set_precision(precision)
         for _ in range(warmup):
             pred = step()
         finish_gather()
         torch.cuda.synchronize()
-        lib.um_timing_enable((1 << 0) | (1 << 1))       # only the kernels the roofline blocks report: window_attn, gsv
-        for kid in range(UM_K_COUNT):
-            collect(lib, kid)
+        lib.um_timing_enable(0)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -269,20 +296,60 @@ def main():
         elapsed = time.perf_counter() - t0
         step_ms.clear()
         step_ms.extend(sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps)))
-        lib.um_timing_enable(0)
         if distributed:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
-        return elapsed, pred, collect(lib, 0), collect(lib, 1), collect(lib, 2)
+        return elapsed, pred
 
-    elapsed, pred, attn_t, gsv_t, split_t = timed(args.precision, args.steps, args.warmup)
+    def breakdown(steps):
+        """After the headline region: the same steps with the library's per-kernel hipEvents -- one pass timing only the launches
+        INSIDE the CNN encoder, one pass timing only those outside it (hooks on the backbone flip the timing mask; nothing is
+        synchronised inside a step).  Returns ({kernel id: (ms, launches)} outside, the same inside, encoder wall ms per step)."""
+        out = []
+        spans = []
+        for inside in (False, True):
+            state = {'e0': None}
+
+            def pre(_m, _a, inside=inside, state=state):
+                lib.um_timing_enable(-1 if inside else 0)
+                if inside:
+                    state['e0'] = torch.cuda.Event(enable_timing=True)
+                    state['e0'].record()
+
+            def post(_m, _a, _o, inside=inside, state=state):
+                lib.um_timing_enable(0 if inside else -1)
+                if inside:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    spans.append((state['e0'], e1))
+            h1 = model.backbone.register_forward_pre_hook(pre)
+            h2 = model.backbone.register_forward_hook(post)
+            torch.cuda.synchronize()
+            for kid in range(UM_K_COUNT):
+                collect(lib, kid)
+            lib.um_timing_enable(0 if inside else -1)
+            for _ in range(steps):
+                step()
+            finish_gather()
+            torch.cuda.synchronize()
+            lib.um_timing_enable(0)
+            out.append({kid: collect(lib, kid) for kid in range(UM_K_COUNT)})
+            h1.remove()
+            h2.remove()
+        enc_wall = sum(a.elapsed_time(b_) for a, b_ in spans) / max(len(spans), 1)
+        return out[0], out[1], enc_wall
+
+    elapsed, pred = timed(args.precision, args.steps, args.warmup)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     spread_ms = (step_ms[0], step_ms[-1])
+    hot_t, enc_t, enc_wall_ms = breakdown(args.steps)
     other = 'fast' if args.precision == 'exact' else 'exact'
     extra = None
     if not args.no_fast:
-        extra = timed(other, args.steps, max(2, args.warmup // 2))
+        e_el, e_pred = timed(other, args.steps, max(2, args.warmup // 2))
+        extra = (e_el, e_pred) + breakdown(args.steps)
+        model.set_precision(args.precision)
     rccl_ranks = gather.ranks() if gather is not None else 1
 
     if rank != 0:
@@ -291,17 +358,52 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- algorithmic work: feature map 64x96, L=6144, C=128, K=2 -> n=1536, 2B streams
-    h, w, c = HEIGHT // 8, WIDTH // 8, 128
-    L, n = h * w, (h // 2) * (w // 2)
-    attn_flops = 4.0 * (2 * b) * L * n * c                          # QK^T + PV per launch
+    # ---- algorithmic work per step on THIS rank: per scale, feature map h x w, L = h w, C = 128, K splits -> n = L / K^2,
+    # S = 2 b streams; 12 attention launches, 6 FFN launches per scale; global correlation + global propagation at scale 0
+    c = 128
+    scales = [(HEIGHT // 8, WIDTH // 8, 2)] if not cfg4 else [(HEIGHT // 8, WIDTH // 8, 2), (HEIGHT // 4, WIDTH // 4, 8)]
+    S = 2 * b
+    attn_flops = sum(12 * 4.0 * S * (h * w) * ((h // k) * (w // k)) * c for h, w, k in scales)
     attn_fused = 0.0
     if getattr(model.ops, 'fused_merge', False):
-        attn_fused += 2.0 * (2 * b) * L * c * c                     # the merge Linear folded into the epilogue
+        attn_fused += sum(12 * 2.0 * S * h * w * c * c for h, w, _ in scales)       # the merge Linear folded into the epilogue
         if getattr(model.ops, 'fused_qproj', False):
-            attn_fused += 2.0 * (2 * b) * L * c * c                 # the query projection folded into the prologue
-    gsv_flops = b * (2.0 * L * L * c + 4.0 * L * L)                 # per launch (corr or propagation)
-    roof, roof2 = rooflines(attn_t, gsv_t, attn_flops, gsv_flops, args.precision, b, attn_fused)
+            attn_fused += sum(12 * 2.0 * S * h * w * c * c for h, w, _ in scales)   # the query projection folded into the prologue
+    L0 = scales[0][0] * scales[0][1]
+    gsv_flops = 2 * b * (2.0 * L0 * L0 * c + 4.0 * L0 * L0)       # correlation + propagation launch at scale 0
+    ffn_flops = sum(6 * 2.0 * S * h * w * 1024 * 384 for h, w, _ in scales)
+    n_attn, n_gsv, n_ffn = 12 * len(scales), 2, 6 * len(scales)
+
+    def blocks(hot, precision):
+        from unimatch_amd.ops import HipOps
+        tag = 'Fp16, 2' if precision == 'exact' else 'Bf16, 1'
+        pmc_ok = (not cfg4) and b == BATCH
+        f_, r_, k_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.um_window_attn_plan(S, HEIGHT // 8, WIDTH // 8, HEIGHT // 16, WIDTH // 16, ctypes.byref(f_), ctypes.byref(r_), ctypes.byref(k_))
+        ksplit = 'true' if r_.value > 0 else 'false'
+        r1 = roofline_block('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, {ksplit}>",
+                            ['window_attn.hip', 'common.h'], hot[0], attn_flops, n_attn, precision, pmc_ok)
+        if r1 is not None and attn_fused:
+            tot = (attn_flops + attn_fused) / (hot[0][0] * 1e-3 / (hot[0][1] / n_attn))
+            issued = 3.0 if precision == 'exact' else 1.0
+            r1['with_fused_linears'] = {
+                'note': 'the same launches also execute transformer.py:58 (q projection, prologue) and :137 (merge Linear, '
+                        'epilogue; LayerNorm + residual not counted)',
+                'algorithmic_gflop_per_launch': round((attn_flops + attn_fused) / n_attn / 1e9, 2), 'achieved': round(tot / 1e12, 2),
+                'frac': round(tot / PEAK_MFMA_16BIT, 4), 'issued_mfma_frac': round(tot * issued / PEAK_MFMA_16BIT, 4)}
+        r2 = roofline_block('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
+                            hot[1], gsv_flops, n_gsv, precision, pmc_ok)
+        r3 = roofline_block('ffn_kernel (whole Transformer FFN, one launch)', f'ffn_kernel<{tag}, false>', ['ffn.hip', 'common.h'],
+                            hot[10], ffn_flops, n_ffn, precision, pmc_ok)
+        return r1, r2, r3
+
+    def sums(hot, enc, steps):
+        per = {KERNEL_NAMES[k]: round(v[0] / steps, 4) for k, v in hot.items() if v[1]}
+        return (round(sum(v[0] for v in hot.values()) / steps, 3), per, round(sum(v[0] for v in enc.values()) / steps, 3),
+                {KERNEL_NAMES[k]: round(v[0] / steps, 4) for k, v in enc.items() if v[1]})
+
+    roof, roof2, roof3 = blocks(hot_t, args.precision)
+    hot_ms, hot_per, enc_ms, enc_per = sums(hot_t, enc_t, args.steps)
 
     # ---- baselines + EPE (rank 0 of the 1-GPU run only): bounded samples of the same workload shape, one pair
     cpu, eager, epe, epe_other = None, None, {}, None
@@ -330,7 +432,7 @@ def main():
             iters += 1
         cpu_s = (time.perf_counter() - t1) / max(iters, 1)
         cpu = {'value': round(1.0 / cpu_s, 4), 'unit': 'pairs/s', 'cores': best_t, 'kind': 'port',
-               'host_cores': ncores,
+               'host_cores': ncores, 'cpu_model': cpu_model_string(), 'torch_threads': torch.get_num_threads(),
                'sample': f'{iters} forwards of 1 pair {HEIGHT}x{WIDTH} (fp32 torch-CPU port of the reference, '
                          f'pinned to it by tests/golden), {cpu_s:.2f} s each'}
         truth = om.unimatch_forward(sd, c0.double(), c1.double(), **okw)     # fp64 evaluation = ground truth
@@ -342,9 +444,8 @@ def main():
                'gpu_vs_cpu_fp32': round(_epe(g, ref), 6), 'precision': args.precision,
                'note': 'mean end-point error in pixels at full resolution on 1 sample pair; the middle figure is '
                        'the fp32 reference-port noise floor at random-init weights.  Every sample of the batch, both image '
-                       'kinds, 3 seeds, all five configs at their own batch: profiles/r03_parity_batch.txt (weights: the '
-                       'reference constructor under seed 326, and the BUILDER-DEFINED conditioned set synth.CONDITIONED for '
-                       'the absolute 1e-3 px gate)'}
+                       'kinds, 3 seeds, all five configs at their own batch: profiles/r03_parity_batch.txt; configs 3 / 4 (chaotic '
+                       'end to end at random init) stage by stage on the reference constructor\'s weights: profiles/r04_stage_parity.txt'}
         if extra is not None:
             epe_other = round(_epe(extra[1][:1].cpu(), truth), 6)
         # the same port on this GPU with stock PyTorch-ROCm eager ops (factories default to the device inside the context)
@@ -370,38 +471,56 @@ def main():
 
     fast_obj = None
     if extra is not None:
-        e_el, _, e_attn, e_gsv, _ = extra
-        r1, r2 = rooflines(e_attn, e_gsv, attn_flops, gsv_flops, other, b, attn_fused)
+        e_el, _, e_hot, e_enc, _ = extra
+        r1, r2, r3 = blocks(e_hot, other)
+        e_hot_ms, _, e_enc_ms, _ = sums(e_hot, e_enc, args.steps)
         fast_obj = {'precision': other, 'dtype': 'bf16' if other == 'fast' else 'f16x2',
-                    'value': round(world * b * args.steps / e_el, 3), 'unit': 'pairs/s',
-                    'ms_per_step': round(e_el / args.steps * 1e3, 3), 'roofline': r1, 'roofline_global_corr': r2,
+                    'value': round(gb * args.steps / e_el, 3), 'unit': 'pairs/s',
+                    'ms_per_step': round(e_el / args.steps * 1e3, 3), 'roofline': r1, 'roofline_global_corr': r2, 'roofline_ffn': r3,
+                    'hot_path_ms_per_step': e_hot_ms, 'encoder_ms_per_step': e_enc_ms,
                     'epe_vs_fp64_truth': epe_other,
                     'note': 'same workload and steps in the other operand precision; reported beside the headline, not a parity claim'}
 
-    pairs = world * b * args.steps
+    pairs = gb * args.steps
     value = pairs / elapsed
+    if cfg4:
+        workload = (f'GMFlow scale-2 + 6 refinements (BASELINE.json configs[3]), GLOBAL batch {gb} x {HEIGHT}x{WIDTH} sharded over '
+                    f'{world} rank(s) ({b} pairs on rank 0), swin K=[2,8], global + local (r=4) correlation, global + local propagation, '
+                    'random-init weights')
+    else:
+        workload = (f'GMFlow scale-1 flow, batch {b} x {HEIGHT}x{WIDTH} per GPU, swin K=2, global '
+                    'correlation + global propagation, random-init weights')
     line = {
         'metric': 'image_pairs_per_sec', 'value': round(value, 3), 'unit': 'pairs/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'ms_per_step_median': round(median_ms, 3), 'ms_per_step_min_max': [round(spread_ms[0], 3), round(spread_ms[1], 3)],
-        'pairs_per_sec_at_median': round(b / (median_ms * 1e-3), 2),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'pairs_per_sec_at_median': round((gb if cfg4 else b) / (median_ms * 1e-3), 2),
+        'higher_is_better': True, 'scaling': 'strong' if cfg4 else 'weak', 'vs_baseline': None,
         'dtype': 'f16x2' if args.precision == 'exact' else 'bf16',
         'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,
-        'config': {'workload': f'GMFlow scale-1 flow, batch {b} x {HEIGHT}x{WIDTH} per GPU, swin K=2, global '
-                               'correlation + global propagation, random-init weights',
-                   'per_gpu_batch': b, 'global_batch': world * b, 'precision': args.precision,
+        'config': {'workload': workload,
+                   'per_gpu_batch': b, 'global_batch': gb, 'precision': args.precision,
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; every '
                                      'GEMM / convolution of the forward runs on the library\'s own split-fp16 MFMA kernels '
                                      '(no MIOpen, hipBLASLt or rocBLAS kernel in the forward)',
-                   'parallelism': (f'dp{world} (batch-sharded, um_allgather_preds = ncclAllGather of predictions, side stream)'
+                   'parallelism': ((f'dp{world} (batch-sharded through ShardedUniMatch, um_allgather_preds = ncclAllGather of the predictions on the compute stream)'
+                                    if cfg4 else
+                                    f'dp{world} (batch-sharded, um_allgather_preds = ncclAllGather of predictions, side stream)')
                                    if distributed else 'single GPU'),
                    'weights': 'synth_state_dict(seed 326): per-parameter seeded generator with the reference initialisers\' '
                               'statistics (xavier-uniform / kaiming-normal), rebuilt identically on any box'},
-        'roofline': roof, 'roofline_global_corr': roof2,
-        'timing_note': 'roofline kernel durations come from hipEvent pairs recorded around each window_attn / gsv launch '
-                       'INSIDE the timed steps (28 records per step); value is therefore slightly pessimistic',
-        'split_planes_ms_per_step': round(split_t[0] / args.steps, 3) if split_t[1] else None,
+        'roofline': roof, 'roofline_global_corr': roof2, 'roofline_ffn': roof3,
+        'hot_path_ms_per_step': hot_ms, 'encoder_ms_per_step': enc_ms,
+        'encoder_wall_ms_per_step': round(enc_wall_ms, 3),
+        'hot_path_kernels_ms_per_step': hot_per, 'encoder_kernels_ms_per_step': enc_per,
+        'untimed_ms_per_step': round(median_ms - hot_ms - enc_ms, 3),
+        'hot_path_pairs_per_sec': round((b if not cfg4 else b) / (hot_ms * 1e-3), 1) if hot_ms else None,
+        'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps).  roofline durations, '
+                       'hot_path_ms_per_step (kernel-duration sum of everything outside the CNN encoder = SURVEY 8\'s path) and '
+                       'encoder_ms_per_step (the encoder\'s launches, SURVEY 2 #8, out of scope) come from a separate breakdown '
+                       'pass of the same K steps with per-kernel hipEvents on the launch stream; hot_path_pairs_per_sec = this '
+                       'rank\'s pairs / hot_path_ms_per_step; untimed_ms_per_step = median step - both sums (ATen element-wise ops such '
+                       'as the position add, a few sub-10-us glue kernels, launch gaps)',
         'fast' if other == 'fast' else 'exact': fast_obj,
         'cpu_baseline': cpu, 'rocm_eager_baseline': eager, 'epe': epe or None,
         'speedup_vs_cpu_port': None if cpu is None else round(value / cpu['value'], 1),

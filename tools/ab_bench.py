@@ -58,7 +58,8 @@ def main():
                 d = json.loads(out.stdout.strip().splitlines()[-1])
                 print(f'{label:20s} {d["value"]:9.2f} pairs/s  {d["ms_per_step"]:8.3f} ms/step  '
                       f'window_attn {d["roofline"]["avg_launch_ms"]:.4f} ms  gsv4 {d["roofline_global_corr"]["avg_launch_ms"]:.4f} ms  '
-                      f'median {d.get("ms_per_step_median", 0):.3f}', flush=True)
+                      f'ffn {(d.get("roofline_ffn") or {}).get("avg_launch_ms", 0):.4f} ms  hot path {d.get("hot_path_ms_per_step", 0):.3f} ms  '
+                      f'encoder {d.get("encoder_ms_per_step", 0):.3f} ms  median {d.get("ms_per_step_median", 0):.3f}', flush=True)
             except (IndexError, ValueError, KeyError):
                 print(f'{label:20s} FAILED\n{out.stderr[-800:]}', flush=True)
 

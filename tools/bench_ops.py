@@ -17,6 +17,8 @@ from unimatch_amd.ops import HipOps  # noqa: E402
 KNAMES = ['window_attn', 'gsv', 'split_planes', 'local_corr', 'cost_volume', 'prop_local', 'depth_corr', 'linear',
           'instance_norm', 'convex_upsample', 'ffn', 'conv']
 PEAK = 2.5e15
+PEAK_HBM = 8.0e12           # B/s, MI355X_MICROARCH.md
+PEAK_VALU_F32 = 157.3e12    # FLOP/s fp32 vector FMA, MI355X_MICROARCH.md
 
 
 def collect(lib):
@@ -29,7 +31,9 @@ def collect(lib):
     return out
 
 
-def run(label, fn, flops, lib, iters, kernel, issued=1.0):
+def run(label, fn, flops, lib, iters, kernel, issued=1.0, min_bytes=None):
+    """``min_bytes``: the kernel is a gather / short-reduction kernel (K3, K4, K6, K7) -- its rooflines are HBM
+    (compulsory bytes / time against 8 TB/s) and fp32 VALU (algorithmic FLOPs / time against 157 TF/s), not the matrix pipe."""
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -43,6 +47,11 @@ def run(label, fn, flops, lib, iters, kernel, issued=1.0):
     ms = t[kernel][0]
     extra = ' '.join(f'{k}={v[0] * v[1] / iters:.3f}ms' for k, v in t.items() if k != kernel)
     tf = flops / (ms * 1e-3) / 1e12
+    if min_bytes is not None:
+        gbs = min_bytes / (ms * 1e-3)
+        print(f'{label:46s} {ms:8.4f} ms  HBM {gbs / 1e9:8.1f} GB/s of {min_bytes / 1e6:7.1f} MB compulsory ({100 * gbs / PEAK_HBM:5.2f}% of 8 TB/s)  '
+              f'VALU {tf:6.2f} TF/s fp32 ({100 * tf * 1e12 / PEAK_VALU_F32:5.2f}% of 157 TF/s)  [{extra}]', flush=True)
+        return
     print(f'{label:46s} {ms:8.4f} ms  {tf:8.1f} TF/s alg ({100 * tf * 1e12 / PEAK:5.2f}% peak, issued {100 * tf * issued * 1e12 / PEAK:5.2f}%)  [{extra}]',
           flush=True)
 
@@ -160,16 +169,31 @@ def main():
         L = h * w
         f0, f1 = (torch.randn(B, L, C, device=dev, generator=g) for _ in range(2))
         flow = torch.randn(B, 2, h, w, device=dev, generator=g) * 3
-        run('cost volume cfg4 B=4 128x192 r=4', lambda: ops.local_corr_with_flow(f0, f1, flow, h, w, 4),
-            2.0 * B * L * 100 * C, lib, iters, 'cost_volume')
+        # compulsory traffic: both feature maps once (fp32) + the flow + the output
+        k4_bytes = B * (2.0 * L * C * 4 + 8.0 * L + 4.0 * 81 * L)
+        k3_bytes = B * (2.0 * L * C * 4 + 8.0 * L)
+        k6_bytes = B * (2.0 * L * C * 4 + 2 * 8.0 * L)
+        run('cost volume cfg4 B=4 128x192 r=4 (incoherent)', lambda: ops.local_corr_with_flow(f0, f1, flow, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume', min_bytes=k4_bytes)
         yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
         smooth = torch.stack([6.3 * torch.sin(yy / 23.0) + 0.01 * xx, 4.1 * torch.cos(xx / 31.0)], 0)[None].repeat(B, 1, 1, 1).contiguous()
-        run('cost volume, smooth flow (4-pixel blocking)', lambda: ops.local_corr_with_flow(f0, f1, smooth, h, w, 4),
-            2.0 * B * L * 100 * C, lib, iters, 'cost_volume')
+        run('cost volume, smooth flow (MFMA tiles)', lambda: ops.local_corr_with_flow(f0, f1, smooth, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume', min_bytes=k4_bytes)
+        ops.k4_mfma = False
+        run('cost volume VALU kernel, incoherent flow', lambda: ops.local_corr_with_flow(f0, f1, flow, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume', min_bytes=k4_bytes)
+        run('cost volume VALU kernel, smooth flow', lambda: ops.local_corr_with_flow(f0, f1, smooth, h, w, 4),
+            2.0 * B * L * 100 * C, lib, iters, 'cost_volume', min_bytes=k4_bytes)
+        ops.k4_mfma = True
         run('local corr softmax cfg4 B=4 128x192 r=4', lambda: ops.local_corr_softmax(f0, f1, h, w, 4),
-            2.0 * B * L * 81 * C, lib, iters, 'local_corr')
+            2.0 * B * L * 81 * C, lib, iters, 'local_corr', min_bytes=k3_bytes)
+        # config 3 scale 1: 1-D local correlation (9 taps) on 128 x 240
+        h3, w3 = 128, 240
+        s0, s1 = (torch.randn(B, h3 * w3, C, device=dev, generator=g) for _ in range(2))
+        run('local corr softmax 1-D cfg3 B=4 128x240 r=4', lambda: ops.local_corr_softmax(s0, s1, h3, w3, 4, one_d=True),
+            2.0 * B * h3 * w3 * 9 * C, lib, iters, 'local_corr', min_bytes=B * (2.0 * h3 * w3 * C * 4 + 4.0 * h3 * w3))
         run('prop local cfg4 B=4 128x192 r=1', lambda: ops.prop_local(f0, f1, flow, h, w, 1),
-            2.0 * B * L * 9 * C, lib, iters, 'prop_local')
+            2.0 * B * L * 9 * C + 2.0 * B * L * 9 * 2, lib, iters, 'prop_local', min_bytes=k6_bytes)
         # config 5: plane-sweep depth correlation, 16 samples of 60x80, 64 inverse-depth candidates, a sideways camera move
         B5, h5, w5, D = 16, 60, 80, 64
         g0, g1 = (torch.randn(B5, h5 * w5, C, device=dev, generator=g) for _ in range(2))
@@ -179,7 +203,8 @@ def main():
         cam = cam1[None].repeat(B5, 1).contiguous().to(dev)
         cand = torch.linspace(1 / 10.0, 1 / 0.5, D, device=dev)
         run('depth corr softmax cfg5 B=16 60x80 D=64', lambda: ops.depth_corr_softmax(g0, g1, h5, w5, cam, cand),
-            2.0 * B5 * h5 * w5 * D * 4 * C, lib, iters, 'depth_corr')
+            2.0 * B5 * h5 * w5 * D * C + 8.0 * B5 * h5 * w5 * D * C, lib, iters, 'depth_corr',
+            min_bytes=B5 * (2.0 * h5 * w5 * C * 4 + 4.0 * h5 * w5))
 
 
 if __name__ == '__main__':
