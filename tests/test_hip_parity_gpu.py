@@ -1015,6 +1015,12 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         assert err(_to_map(o0, h, w), want0)[0] < 2e-4, tag
         assert err(_to_map(o1, h, w), want1)[0] < 2e-4, tag
         assert err(_to_map(o0, h, w), g[f'{tag}.o0'])[0] < 4e-4, tag
+        # round 4: both layers' k | v projections of a block as ONE launch (N = 512) -- the same per-column-tile GEMMs on the
+        # same operands as the two launches it replaces: bitwise equal
+        per_layer = HipOps('exact')
+        per_layer.block_kv = False
+        p0, p1 = proto(per_layer, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
+        assert torch.equal(p0, o0) and torch.equal(p1, o1), tag
 
 
 @pytest.mark.parametrize('hw', [(24, 36), (64, 96), (256, 384), (400, 320)])

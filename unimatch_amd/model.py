@@ -108,12 +108,14 @@ class TransformerLayer(nn.Module):
                                      nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
             self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, ops, source, target, h, w, geom, kv_rotate=0):
+    def forward(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None):
         """``kv_rotate = r`` (fused path only): ``target`` holds the streams in the SAME order as ``source`` and stream ``s``
-        attends the keys / values of stream ``(s + r) mod S`` -- the swapped copy ``[f1; f0]`` is never built."""
+        attends the keys / values of stream ``(s + r) mod S`` -- the swapped copy ``[f1; f0]`` is never built.
+        ``kv = (planes, rows, cols, k_offset, v_offset)``: the layer's key / value projections of ``target`` already exist as
+        operand planes (the block projects both layers' k | v in one launch, or the previous block's FFN epilogue wrote them)."""
         if getattr(ops, 'fused_tail', False):
-            return self._forward_fused(ops, source, target, h, w, geom, kv_rotate)
-        assert kv_rotate == 0
+            return self._forward_fused(ops, source, target, h, w, geom, kv_rotate, kv)
+        assert kv_rotate == 0 and kv is None
         q, k, v = self.q_proj(source), self.k_proj(target), self.v_proj(target)
         msg = ops.window_attention(q, k, v, h, w, *geom)
         msg = self.norm1(self.merge(msg))
@@ -121,7 +123,7 @@ class TransformerLayer(nn.Module):
             msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
         return source + msg
 
-    def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0):
+    def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None):
         """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
         (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``)."""
         s, l, c = source.shape
@@ -129,9 +131,14 @@ class TransformerLayer(nn.Module):
         src = source.reshape(m, c)
         if getattr(ops, 'fused_qproj', False) and getattr(ops, 'fused_merge', False):
             # q is projected inside the attention kernel's prologue (um_window_attn_qproj_merge_fwd): only k | v planes exist
-            kv, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
+            if kv is None:
+                kvp, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
+                koff, voff = 0, c
+            else:
+                kvp, rows, n2, koff, voff = kv
+                assert rows == m
             res = src if self.no_ffn else None
-            msg = ops.window_attention_qproj_merge(src, self.q_proj.weight, (kv, m, n2, 0), (kv, m, n2, c), s, h, w, *geom,
+            msg = ops.window_attention_qproj_merge(src, self.q_proj.weight, (kvp, m, n2, koff), (kvp, m, n2, voff), s, h, w, *geom,
                                                    kv_rotate, self.merge.weight, self.norm1, res)
             if self.no_ffn:
                 return msg
@@ -140,6 +147,7 @@ class TransformerLayer(nn.Module):
                 return ops.ffn_ln(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2).reshape(s, l, c)
             hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)
             return ops.linear_ln(hid, (self.mlp[2].weight,), self.norm2, residual=src, a_planes_k=nh).reshape(s, l, c)
+        assert kv is None, 'precomputed k | v planes need the fused q-projection / merge path'
         if target is source:                       # self attention: one projection launch for q | k | v
             qkv, _, n3 = ops.linear_planes(src, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight))
             q, k, v = (qkv, m, n3, 0), (qkv, m, n3, c), (qkv, m, n3, 2 * c)
@@ -193,13 +201,24 @@ class FeatureTransformer(nn.Module):
         b = stream.shape[0] // 2
         rotate = getattr(ops, 'fused_tail', False)     # cross-attention target [f1; f0] = `prev` read with the halves rotated
         prev = stream if rotate else torch.cat([stream[b:], stream[:b]], 0)
+        # both layers of a block read their keys / values from the stream AS IT ENTERS the block (self: the stream itself; cross:
+        # its halves rotated), so the four projections Wk_self | Wv_self | Wk_cross | Wv_cross are ONE launch that reads the
+        # stream once (round 4; was two launches of two projections each: transformer.py:58-60 per layer)
+        block_kv = rotate and getattr(ops, 'fused_qproj', False) and getattr(ops, 'fused_merge', False) and getattr(ops, 'block_kv', True)
+        s2, l, c = stream.shape
         for i, blk in enumerate(self.layers):
             shift = ('swin' in attn_type) and attn_num_splits > 1 and i % 2 == 1
             g_self = attention_windows(attn_type, True, attn_num_splits, h, w, shift)
             g_cross = attention_windows(attn_type, False, attn_num_splits, h, w, shift)
-            stream = blk.self_attn(ops, stream, stream, h, w, g_self)
+            kv_s = kv_c = None
+            if block_kv:
+                sa, ca = blk.self_attn, blk.cross_attn_ffn
+                kv4, m, n4 = ops.linear_planes(stream.reshape(s2 * l, c), (sa.k_proj.weight, sa.v_proj.weight,
+                                                                         ca.k_proj.weight, ca.v_proj.weight))
+                kv_s, kv_c = (kv4, m, n4, 0, c), (kv4, m, n4, 2 * c, 3 * c)
+            stream = blk.self_attn(ops, stream, stream, h, w, g_self, kv=kv_s)
             if rotate:                                 # keys / values come from the stream as it was before this block
-                stream, prev = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b), None
+                stream, prev = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b, kv=kv_c), None
                 prev = stream
             else:
                 stream = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross)

@@ -61,6 +61,7 @@ class HipOps:
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
     fused_merge = True         # merge + LayerNorm (+ residual) in the attention kernel's epilogue
     fused_qproj = True         # ... and the query projection in its prologue (um_window_attn_qproj_merge_fwd)
+    block_kv = True            # one k | v projection launch per Transformer block (both layers' keys / values, N = 512)
     # (class attributes: tests and tools/ab_bench.py flip them programmatically; the product reads no environment variable)
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
