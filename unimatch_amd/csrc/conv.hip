@@ -25,6 +25,11 @@
 //                      all nine taps (the default for every 3x3 layer of the encoder and the refinement block)
 #include <cstdlib>
 #include <cstring>
+// -DUM_CONV_2P=1|2 (diagnostic builds: profiles/r04_precision_budget_conv.txt): two MFMA products instead of three -- 1 drops
+// W_lo . A_hi (weights effectively rounded to one fp16 plane), 2 drops W_hi . A_lo (activations in one plane).
+#ifndef UM_CONV_2P
+#define UM_CONV_2P 0
+#endif
 #include "common.h"
 #include "planes.h"
 
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
                 const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 64 + foff[ks]);
                 if (NS == 2) {
                     const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 64 + foff[ks]);
-                    acc[nt] = T::mfma(wl, bh, acc[nt]);
-                    acc[nt] = T::mfma(wh, bl, acc[nt]);
+                    if (UM_CONV_2P != 1) acc[nt] = T::mfma(wl, bh, acc[nt]);
+                    if (UM_CONV_2P != 2) acc[nt] = T::mfma(wh, bl, acc[nt]);
                 }
                 acc[nt] = T::mfma(wh, bh, acc[nt]);
             }
@@ -611,8 +616,8 @@ __global__ __launch_bounds__(512, (NSLOT == 2 && NT < 4 ? 2 : 1)) void conv_rows
                 const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 32 + foffw);
                 if (NS == 2) {
                     const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 32 + foffw);
-                    acc[nt] = T::mfma(wl, bh, acc[nt]);
-                    acc[nt] = T::mfma(wh, bl, acc[nt]);
+                    if (UM_CONV_2P != 1) acc[nt] = T::mfma(wl, bh, acc[nt]);
+                    if (UM_CONV_2P != 2) acc[nt] = T::mfma(wh, bl, acc[nt]);
                 }
                 acc[nt] = T::mfma(wh, bh, acc[nt]);
             }
@@ -764,8 +769,8 @@ __global__ __launch_bounds__(512, (NT < 4 ? 2 : 1)) void conv_patch_kernel(ConvA
                     const i16x8 wh = *reinterpret_cast<const i16x8*>(wt + nt * 32 * 32 + foffw);
                     if (NS == 2) {
                         const i16x8 wl = *reinterpret_cast<const i16x8*>(wt + WTILE + nt * 32 * 32 + foffw);
-                        acc[nt] = T::mfma(wl, bh, acc[nt]);
-                        acc[nt] = T::mfma(wh, bl, acc[nt]);
+                        if (UM_CONV_2P != 1) acc[nt] = T::mfma(wl, bh, acc[nt]);
+                        if (UM_CONV_2P != 2) acc[nt] = T::mfma(wh, bl, acc[nt]);
                     }
                     acc[nt] = T::mfma(wh, bh, acc[nt]);
                 }

@@ -33,6 +33,15 @@
 #include "common.h"
 #include "planes.h"
 
+// -DUM_FFN_TRACE (diagnostic builds; tools/trace_ffn.py): lane 0 of waves 0 and 4 (the two roles of pair 0) of every 37th workgroup
+// stamps s_memtime at the section boundaries of its first 24 slices into the buffer given to um_debug_set_ffn_trace().
+#ifdef UM_FFN_TRACE
+__device__ unsigned long long* g_um_ffn_trace = nullptr;
+#define UM_FSTAMP(slot) do { if (tracing && i < 24) trace_buf[(i) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UM_FSTAMP(slot) do { } while (0)
+#endif
+
 struct FfnArgs {
     const float* x;               // [M, 128] source; also the residual
     const float* y;               // [M, 128] message
@@ -62,6 +71,15 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
                  : "memory");
 }
 
+// Main-loop order (round 4).  1: phase A of slice i+1 FIRST, then phase B of slice i-1; the LDS-DMA statements of the next weight
+// slices ride in the gaps of the phase-A MFMAs instead of standing between the barrier and the first MFMA, the exchange read is
+// issued right behind the barrier, and the accumulator hand-over (add, send) happens in the gaps of phase B -- so the stretch of a
+// slice in which BOTH waves of a SIMD (they run in lockstep: one workgroup barrier per slice) leave the matrix pipe idle shrinks
+// from [tail + barrier + DMA issue + exchange + first fragments] to [barrier + first fragments].  0: the round-1..3 order (B then
+// A, DMA right after the barrier, hand-over after the stream).  Same arithmetic in the same order per accumulator: bitwise equal.
+#ifndef UM_FFN_ORDER
+#define UM_FFN_ORDER 1
+#endif
 #ifndef UM_FFN_ABL
 #define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
 #endif
@@ -169,6 +187,29 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl)
             ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
+    };
+
+#ifdef UM_FFN_TRACE
+    const bool tracing = g_um_ffn_trace != nullptr && (blockIdx.x % 37) == 0 && lane == 0 && pair == 0;
+    unsigned long long* trace_buf = g_um_ffn_trace + ((size_t)(blockIdx.x / 37) * 2 + role) * (24 * 8 + 8);
+    if (tracing) trace_buf[24 * 8] = __builtin_amdgcn_s_memtime();
+#endif
+    // the same six statements one at a time (UM_FFN_ORDER 1: they are issued in the gaps of the phase-A MFMAs)
+    auto dma_piece = [&](int k, int jw1, int jw2, int slot) {      // k = 0..3: W1 (i = k >> 1, plane k & 1), 4..5: W2 plane k - 4
+        if (k < 4) {
+            const int i = k >> 1, pl = k & 1;
+            if (pl >= NS) return;
+            const int blk = 8 * i + wave;
+            const int r = 2 * blk + half, c = tl ^ r;
+            const unsigned off = (unsigned)((((long)(32 * (sbase + jw1) + r)) * 256 + 8 * c) * 2);
+            ffn_dma16(a.w1 + pl * a.w1_plane_stride, off, lds + L::W1_OFF + slot * L::W1S + pl * L::W1P + blk * 1024);
+        } else {
+            const int pl = k - 4;
+            if (pl >= NS) return;
+            const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+            const unsigned off = (unsigned)((((long)r) * a.hid + 32 * (sbase + jw2) + 8 * c) * 2);
+            ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
+        }
     };
 
     dma_w1(0, 0);
@@ -319,8 +360,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         const int slot = i & 1;
         const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
         const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
+        UM_FSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(i+1), W2(i-1): this thread's pieces have landed
+        UM_FSTAMP(1);
         __syncthreads();
+        UM_FSTAMP(2);
         if (!(UM_FFN_ABL & 2)) {
             if (i + 2 < nslice) dma_w1(i + 2, slot);
             dma_w2(i, slot);
@@ -353,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         f32x16 scn, scm;                                           // phase A alternates two accumulators (see phase B)
 #pragma unroll
         for (int r = 0; r < 16; ++r) scn[r] = scm[r] = 0.f;
+        UM_FSTAMP(3);
         __builtin_amdgcn_s_setprio(1);
         int mslot = 0;
         i16x8 fh[3], fl[3];                                        // phase A fragments, two k-steps ahead of their MFMAs
@@ -407,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        UM_FSTAMP(4);
         for (; done < NSTAGE; ++done) {                            // whatever no MFMA was left to hide
             if (done < NGELU) ffn_gelu_stage(g[done / UM_GELU_STAGES], done % UM_GELU_STAGES);
             else frag_stage(fr, g, pfn, done - NGELU);
@@ -421,10 +467,185 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         }
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl) pf[pl] = pfn[pl];
+        UM_FSTAMP(5);
     };
-    iteration(std::true_type{}, std::false_type{}, 0);
-    for (int i = 1; i + 1 < nslice; ++i) iteration(std::true_type{}, std::true_type{}, i);
-    iteration(std::false_type{}, std::true_type{}, nslice - 1);
+
+    // ---- UM_FFN_ORDER 1: one iteration i (after barrier i) --------------------------------------------------------------------
+    //     MFMA pipe :  phase A of slice i+1 (24 MFMAs)  then  phase B of slice i-1 (12, fragments built last iteration)
+    //     gaps      :  GELU of slice i + its H^T fragments (as before, one share per MFMA); the LDS-DMA statements of W1(i+2) and
+    //                  W2(i) behind the first phase-A MFMAs; the accumulator hand-over (add, send) behind the first phase-B MFMAs
+    auto iteration1 = [&](auto has_a_tag, auto has_b_tag, auto dma1_tag, int i) {
+        constexpr bool HAS_A = decltype(has_a_tag)::value && !(UM_FFN_ABL & 4);
+        constexpr bool HAS_B = decltype(has_b_tag)::value && !(UM_FFN_ABL & 8);
+        constexpr bool DMA1 = decltype(dma1_tag)::value;           // W1(i+2) exists
+        constexpr int MF = (NS == 2) ? 3 : 1;
+        constexpr int MFB = (NS == 2 && UM_FFN_H1) ? 2 : MF;
+        constexpr int NA = HAS_A ? 8 * MF : 0, NB = HAS_B ? 4 * MFB : 0, NMFMA = NA + NB;
+        constexpr int NGELU = 4 * UM_GELU_STAGES, NSTAGE = NGELU + 4;
+        const int slot = i & 1;
+        const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
+        const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
+        UM_FSTAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(i+1), W2(i-1): this thread's pieces have landed
+        UM_FSTAMP(1);
+        __syncthreads();
+        UM_FSTAMP(2);
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if (!(UM_FFN_ABL & 16)) {                                  // the partner's half of S^T(i): first in the LDS queue
+            const unsigned char* p = xb_in + slot * (8 * L::XB);
+            r0 = *reinterpret_cast<const f32x4*>(p);
+            r1 = *reinterpret_cast<const f32x4*>(p + 1024);
+        }
+        i16x8 fh[3], fl[3];                                        // phase A fragments, two k-steps ahead of their MFMAs
+        if (HAS_A) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
+                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
+            }
+        }
+        Gelu2 g[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                g[q].x[e] = (sc[2 * q + e] + r0[2 * q + e]) * a.out_scale;
+                g[2 + q].x[e] = (sc[4 + 2 * q + e] + r1[2 * q + e]) * a.out_scale;
+            }
+        }
+        Frag fr;
+        i16x8 pfn[NS];
+        int done = 0;
+        auto valu_share = [&](int slot_idx) {
+            const int upto = (slot_idx + 1) * NSTAGE / (NMFMA > 0 ? NMFMA : 1);
+            for (; done < upto; ++done) {
+                if (done < NGELU) ffn_gelu_stage(g[done / UM_GELU_STAGES], done % UM_GELU_STAGES);
+                else frag_stage(fr, g, pfn, done - NGELU);
+            }
+        };
+        // LDS-DMA pieces still to issue: W1(i+2) (4 statements at NS = 2) when it exists, W2(i) (2 statements); one per MFMA gap
+        // from gap 1 on (gap 0 carries the exchange arithmetic)
+        int piece = DMA1 ? 0 : 4;
+        auto dma_share = [&](int slot_idx) {
+            if (UM_FFN_ABL & 2) return;
+            if (slot_idx >= 1 && piece < 6) {
+                dma_piece(piece, i + 2, i, slot);
+                ++piece;
+                if (NS == 1 && (piece == 1 || piece == 3)) ++piece;        // (one plane: pieces 1, 3, 5 do not exist)
+            }
+        };
+        f32x16 scn, scm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scn[r] = scm[r] = 0.f;
+        UM_FSTAMP(3);
+        __builtin_amdgcn_s_setprio(1);
+        int mslot = 0;
+        i16x8 vh[4], vl[4];                                        // phase B's W2 fragments: read in the last gaps of phase A
+        if (HAS_A) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
+                }
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    const i16x8 wa = (NS == 2 && m == 0) ? fl[ks % 3] : fh[ks % 3];
+                    const i16x8 xb = (NS == 2 && m == 1) ? xf[NS - 1][ks] : xf[0][ks];
+                    if ((ks * MF + m) & 1) scm = T::mfma(wa, xb, scm);
+                    else scn = T::mfma(wa, xb, scn);
+                    const int left = NA - 1 - (ks * MF + m);       // gaps of phase A after this one
+                    const bool vread = HAS_B && left < 4;          // the last four gaps: W2 fragment ot = 3 - left
+                    if (vread) {
+                        vh[3 - left] = *reinterpret_cast<const i16x8*>(w2s + boff[3 - left]);
+                        if (NS == 2) vl[3 - left] = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[3 - left]);
+                    }
+                    dma_share(mslot);
+                    valu_share(mslot++);
+                    if ((m == 0 && ks + 2 < 8) || vread) __builtin_amdgcn_sched_group_barrier(0x100, NS, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 16, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (HAS_B) {
+            if (!HAS_A) {
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    vh[ot] = *reinterpret_cast<const i16x8*>(w2s + boff[ot]);
+                    if (NS == 2) vl[ot] = *reinterpret_cast<const i16x8*>(w2s + L::W2P + boff[ot]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MFB; ++m)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    const i16x8 wa = (NS == 2 && m == 0) ? vl[ot] : vh[ot];
+                    const i16x8 hb = (NS == 2 && MFB == 3 && m == 1) ? pf[NS - 1] : pf[0];
+                    o[ot] = T::mfma(wa, hb, o[ot]);
+                    const int bslot = m * 4 + ot;
+                    dma_share(mslot);                              // (only when there was no phase A: the last slice)
+                    if (decltype(has_a_tag)::value) {
+                        // hand-over of S^T(i+1): the last phase-A MFMAs retire under the first phase-B MFMAs
+                        if (bslot == 2) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) scn[r] += scm[r];
+                        }
+                        if (bslot == 3) {
+#pragma unroll
+                            for (int r = 8; r < 16; ++r) scn[r] += scm[r];
+                        }
+                        if (bslot == 4) send(scn, slot ^ 1);
+                    }
+                    valu_share(mslot++);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x602, 24, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        UM_FSTAMP(4);
+        for (; done < NSTAGE; ++done) {
+            if (done < NGELU) ffn_gelu_stage(g[done / UM_GELU_STAGES], done % UM_GELU_STAGES);
+            else frag_stage(fr, g, pfn, done - NGELU);
+        }
+        if (!(UM_FFN_ABL & 2)) {
+            while (piece < 6) {                                    // pieces no gap took (ablation builds without MFMAs)
+                dma_piece(piece, i + 2, i, slot);
+                ++piece;
+                if (NS == 1 && (piece == 1 || piece == 3)) ++piece;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(has_a_tag)::value) {
+            if (!HAS_B) {                                          // first slice: no phase B to hide the hand-over in
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scn[r] += scm[r];
+                send(scn, slot ^ 1);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sc[r] = scn[r];
+        }
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) pf[pl] = pfn[pl];
+        UM_FSTAMP(5);
+    };
+
+    if (UM_FFN_ORDER == 1) {
+        using Y = std::true_type;
+        using N = std::false_type;
+        if (2 < nslice) iteration1(Y{}, N{}, Y{}, 0);
+        else iteration1(Y{}, N{}, N{}, 0);
+        int i = 1;
+        for (; i + 2 < nslice; ++i) iteration1(Y{}, Y{}, Y{}, i);
+        for (; i + 1 < nslice; ++i) iteration1(Y{}, Y{}, N{}, i);
+        iteration1(N{}, Y{}, N{}, nslice - 1);
+    } else {
+        iteration(std::true_type{}, std::false_type{}, 0);
+        for (int i = 1; i + 1 < nslice; ++i) iteration(std::true_type{}, std::true_type{}, i);
+        iteration(std::false_type{}, std::true_type{}, nslice - 1);
+    }
     {   // phase B of the last slice
         const unsigned char* w2s = lds + L::W2_OFF + ((nslice - 1) & 1) * L::W2S;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -443,6 +664,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         }
     }
 
+#ifdef UM_FFN_TRACE
+    if (tracing) trace_buf[24 * 8 + 1] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: add the partner's partial O, LayerNorm over the 128 outputs, residual ------------------------------
     __syncthreads();                                               // every ring slot and exchange buffer is dead
     unsigned char* ob = lds + pair * 16384 + lane * 16;
@@ -545,6 +769,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
+#ifdef UM_FFN_TRACE
+extern "C" int um_debug_set_ffn_trace(void* ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_um_ffn_trace), &ptr, sizeof(ptr));
+}
+#endif
 
 template <typename T, int NS, bool HSPLIT>
 static hipError_t launch_ffn_impl(const FfnArgs& a, hipStream_t stream) {

@@ -43,6 +43,17 @@ __device__ unsigned long long* g_um_trace = nullptr;
 #ifndef UM_WATTN_P1
 #define UM_WATTN_P1 0
 #endif
+// Round-4 experiments on the tile loop (diagnostic builds, profiles/r04_attention_experiments.txt):
+//   UM_WATTN_DMA_POS  0: the tile's four LDS-DMA statements ride on QK^T k-steps 0, 2, 4, 6 (rounds 1-3)
+//                     1: they are issued in the softmax phase (VALU only) instead of inside an MFMA phase
+//   UM_WATTN_OFF32    1: staging sources as 32-bit byte offsets from a scalar base (global_load_lds ... v, s[base]) instead of
+//                        64-bit per-lane pointers: half the address registers, no 64-bit arithmetic per tile
+#ifndef UM_WATTN_DMA_POS
+#define UM_WATTN_DMA_POS 0
+#endif
+#ifndef UM_WATTN_OFF32
+#define UM_WATTN_OFF32 0
+#endif
 
 struct WattnArgs {
     const unsigned short* qp;    // planes [NS][S][L][128]
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int NPIECE = 4 * NS;
     const unsigned short* spk[2];
     const unsigned short* spv[2];
+    unsigned sok[2], sov[2];                                             // UM_WATTN_OFF32: byte offsets from a.kp / a.vp
     auto stage_prepare = [&](int t, unsigned char* base) {
         // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
         const bool need = has_mask || (t + 1) * TK > a.n;
@@ -352,9 +364,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const unsigned* tp = tab + t * TK + 8 * wave + ((lane >> 4) & 3);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const long goff = (kvbase + (long)(tp[4 * j] >> 2)) * a.ldkv;
-                spk[j] = a.kp + goff + ssrc_k[j];
-                spv[j] = a.vp + goff + ssrc_v[j];
+                if (UM_WATTN_OFF32) {
+                    const unsigned goff = ((unsigned)kvbase + (tp[4 * j] >> 2)) * (unsigned)a.ldkv;
+                    sok[j] = 2u * (goff + (unsigned)ssrc_k[j]);
+                    sov[j] = 2u * (goff + (unsigned)ssrc_v[j]);
+                } else {
+                    const long goff = (kvbase + (long)(tp[4 * j] >> 2)) * a.ldkv;
+                    spk[j] = a.kp + goff + ssrc_k[j];
+                    spv[j] = a.vp + goff + ssrc_v[j];
+                }
             }
             if (need && tid < 4 * TK) {
                 const int cq = tid >> 5, key = tid & (TK - 1);
@@ -369,9 +387,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             int cls;
             const int tok = token_at(sly[j], slx[j], cls);
             advance(sly[j], slx[j]);
-            const long goff = (kvbase + tok) * a.ldkv;
-            spk[j] = a.kp + goff + ssrc_k[j];
-            spv[j] = a.vp + goff + ssrc_v[j];
+            if (UM_WATTN_OFF32) {
+                const unsigned goff = ((unsigned)kvbase + (unsigned)tok) * (unsigned)a.ldkv;
+                sok[j] = 2u * (goff + (unsigned)ssrc_k[j]);
+                sov[j] = 2u * (goff + (unsigned)ssrc_v[j]);
+            } else {
+                const long goff = (kvbase + tok) * a.ldkv;
+                spk[j] = a.kp + goff + ssrc_k[j];
+                spv[j] = a.vp + goff + ssrc_v[j];
+            }
         }
         if (need && tid < 4 * TK) {
             const int cq = tid >> 5, key = tid & (TK - 1);
@@ -391,9 +415,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int pl = ip >> 1, isv = ip & 1;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(
             base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
+        unsigned keep;
+        if (UM_WATTN_OFF32) {
+            const unsigned short* base = (isv ? a.vp : a.kp) + pl * a.kv_plane_stride;       // wave-uniform: SGPR pair
+            const unsigned o0 = isv ? sov[0] : sok[0];
+            const unsigned o1 = (isv ? sov[1] : sok[1]) - 1024u;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base), "s"(dst) : "memory");
+            return;
+        }
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
         const unsigned short* s1 = (isv ? spv[1] : spk[1]) + pl * a.kv_plane_stride - 512;
-        unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                      "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory");
@@ -444,7 +477,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + koff[ks + 2]);
                     if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks + 2]);
                 }
-                if (staging && (ks * NPAIR) % 8 == 0) stage_pair(ks * NPAIR / 8, nxt);
+                if (UM_WATTN_DMA_POS == 0 && staging && (ks * NPAIR) % 8 == 0) stage_pair(ks * NPAIR / 8, nxt);
                 if (NS == 2) {
                     sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
                     sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
@@ -477,6 +510,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
 
         // ---- online softmax (row max shared by the lane pair l, l^32) ------------------------------------
+        if (UM_WATTN_DMA_POS == 1 && staging) stage_pair(0, nxt);
         float mx = sc[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
@@ -486,6 +520,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             mx = fmaxf(u, v2);
         }
         m = fmaxf(m, mx);
+        if (UM_WATTN_DMA_POS == 1 && staging && NPAIR > 1) stage_pair(1, nxt);
         // Lazy, exact rescale.  The exponent offset M is an integer (every rescale factor is a power of two) and
         // is allowed to lag the true running max by up to LAG: then p <= 2^(LAG + PSHIFT) = 2^15 still fits fp16,
         // and the 64-accumulator rescale -- which otherwise fires on almost every tile because SOME of the wave's
@@ -508,6 +543,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= resc;
         }
+        if (UM_WATTN_DMA_POS == 1 && staging && NPAIR > 2) stage_pair(2, nxt);
         constexpr bool P1 = (NS == 2) && UM_WATTN_P1;           // one P plane (see UM_WATTN_P1)
         constexpr int NSP = P1 ? 1 : NS;
         const float mc = M + (float)PSHIFT;
@@ -518,6 +554,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (!P1) l += p;
         }
 
+        if (UM_WATTN_DMA_POS == 1 && staging && NPAIR > 3) stage_pair(3, nxt);
         // ---- P^T operand fragments: cvt + v_permlane32_swap, no LDS ---------------------------------------
         // k-step ks (16 keys) uses regs 8*ks..8*ks+7; after the swaps a lane holds keys 8*half .. 8*half+7 of
         // the step for its own query (B operand layout).
