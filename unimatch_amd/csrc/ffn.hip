@@ -80,6 +80,15 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 #ifndef UM_FFN_ORDER
 #define UM_FFN_ORDER 1
 #endif
+// Issue priority of the pair's two waves inside the MFMA stream (UM_FFN_ORDER 1).  The partners w and w + 4 share a SIMD and run
+// in lockstep (one workgroup barrier per slice); with equal priority the arbiter serves the OLDER wave (role 0) first, its stream
+// ends ~750 cycles before the partner's (section stamps: 2210 against 2980 cycles per slice), it idles at the barrier and the
+// partner finishes alone with the matrix pipe half used.  1: role 0 favoured in the first half of the stream, role 1 in the second;
+// 2 / 4 / 5: the favoured role alternates every 6 / 3 / 12 MFMAs; 3: role 1 favoured throughout (control); 0: equal priority
+// (rounds 1-3).
+#ifndef UM_FFN_PRIO
+#define UM_FFN_PRIO 0
+#endif
 #ifndef UM_FFN_ABL
 #define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
 #endif
@@ -539,6 +548,17 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         for (int r = 0; r < 16; ++r) scn[r] = scm[r] = 0.f;
         UM_FSTAMP(3);
         __builtin_amdgcn_s_setprio(1);
+        auto prio = [&](int ms) {                                  // ms: compile-time after unrolling; role: wave-uniform
+            int fav = -1;
+            if (UM_FFN_PRIO == 1 && (ms == 0 || ms == NMFMA / 2)) fav = ms == 0 ? 0 : 1;
+            if (UM_FFN_PRIO == 2 && ms % 6 == 0) fav = (ms / 6) & 1;
+            if (UM_FFN_PRIO == 4 && ms % 3 == 0) fav = (ms / 3) & 1;
+            if (UM_FFN_PRIO == 5 && ms % 12 == 0) fav = (ms / 12) & 1;
+            if (UM_FFN_PRIO == 3 && ms == 0) fav = 1;
+            if (fav < 0) return;
+            if (role == fav) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        };
         int mslot = 0;
         i16x8 vh[4], vl[4];                                        // phase B's W2 fragments: read in the last gaps of phase A
         if (HAS_A) {
@@ -552,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 for (int m = 0; m < MF; ++m) {
                     const i16x8 wa = (NS == 2 && m == 0) ? fl[ks % 3] : fh[ks % 3];
                     const i16x8 xb = (NS == 2 && m == 1) ? xf[NS - 1][ks] : xf[0][ks];
+                    prio(mslot);
                     if ((ks * MF + m) & 1) scm = T::mfma(wa, xb, scm);
                     else scn = T::mfma(wa, xb, scn);
                     const int left = NA - 1 - (ks * MF + m);       // gaps of phase A after this one
@@ -583,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 for (int ot = 0; ot < 4; ++ot) {
                     const i16x8 wa = (NS == 2 && m == 0) ? vl[ot] : vh[ot];
                     const i16x8 hb = (NS == 2 && MFB == 3 && m == 1) ? pf[NS - 1] : pf[0];
+                    prio(mslot);
                     o[ot] = T::mfma(wa, hb, o[ot]);
                     const int bslot = m * 4 + ot;
                     dma_share(mslot);                              // (only when there was no phase A: the last slice)

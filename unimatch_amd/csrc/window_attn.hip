@@ -871,6 +871,10 @@ struct WattnPlan {
 
 static WattnPlan wattn_plan(int total, int ntiles, bool can_split) {
     const int slots = 2 * wattn_num_cus();
+    // diagnostic builds (-DUM_DEBUG_SWITCHES): UM_WATTN_FORCE_SPLIT=2|4 key-splits EVERY tile of a big launch (config 2: 768 tiles ->
+    // 1536 half walks = exactly 3 rounds of the 512 resident slots; profiles/r04_attention_experiments.txt)
+    static const int force = [] { const char* e = um_debug_env("UM_WATTN_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
+    if (can_split && force > 1 && ntiles >= 4 * force) return {0, total, force};
     if (can_split && total <= slots) {
         const int split = wattn_key_split(total, ntiles);
         if (split > 1) return {0, total, split};
