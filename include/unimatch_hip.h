@@ -217,6 +217,16 @@ int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const v
                   int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* The key / value projections of BOTH layers of a Transformer block (unimatch/transformer.py:58-60: k_proj / v_proj of the block's
+ * self_attn and of its cross_attn_ffn, four bias-free 128 x 128 Linears of the token stream as it enters the block) in ONE launch
+ * (round 4; two um_linear_fwd launches before):  x fp32 [m][128]  ->  out_planes [NS][4][m][128], the attention kernels' operand
+ * planes in blocked form: projection j (0 k_self, 1 v_self, 2 k_cross, 3 v_cross) is the contiguous [m][128] tensor at element
+ * offset j * m * 128 of every plane (plane stride 4 * m * 128, row stride 128: what um_window_attn_qproj_merge_fwd takes as
+ * k_planes / v_planes + ldkv + kv_plane_stride).  wc_planes = um_weight_planes of the packed [256][256] fp32 matrix
+ *     Wc[32 c + r][0:128] = W4[32 c + r][:],   Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)][:],   c = 0..7, r = 0..31,
+ * W4 = the four weights stacked [512][128] (unimatch_amd/ops.py::kv4_weight_planes builds it). */
+int um_kv4_fwd(const float* x, const void* wc_planes, int m, int wshift, void* out_planes, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolutions either side of the matching path, NHWC, on the matrix cores with the same
  * operand arithmetic as everything else (`mode`): nn.Conv2d of unimatch/reg_refine.py:6-119 (3x3, 1x1, 1x5, 5x1, 7x7)

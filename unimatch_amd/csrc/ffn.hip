@@ -789,6 +789,172 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     }
 }
 
+// =================================================================================================================
+// k | v projections of BOTH layers of a Transformer block in one pass (unimatch/transformer.py:58-60, four bias-free
+// 128 x 128 Linears on the token stream as it enters the block):  out[j] = X . W_j^T,  j = k_self, v_self, k_cross, v_cross,
+// written as the attention kernel's operand planes in BLOCKED form [NS][4][M][128] (every projection its own [M][128] tensor:
+// rows of one projection are contiguous, which the attention kernel's LDS-DMA staging streams ~2 % faster than 256-byte
+// pieces of 1 KB rows).
+//
+// Same machinery as the FFN's first GEMM ("phase A"): workgroup = 8 waves = 128 tokens, wave (pair, role) owns the 32 tokens of
+// its pair; role 0 produces k_self | v_self, role 1 k_cross | v_cross.  The token operand Y^T (all 128 features, hi | lo) stays in
+// registers as B fragments for the whole pass; the 512 weight rows stream through the W1 ring in 8 chunks of (32 rows of role 0's
+// half | 32 rows of role 1's half) laid out exactly like a W1 slice -- so the host packs the four weights as one [256][256]
+// matrix  Wc[32 c + r][0:128] = W4[32 c + r],  Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)]  (role 1 reads ring rows
+// permuted by ^16, see phase A) -- one barrier per chunk, LDS-DMA one chunk ahead.  Each 32 x 32 result tile is converted to
+// fp16 hi | lo, transposed through a wave-private LDS scratch (double-buffered: the global stores of chunk c leave while chunk
+// c + 1 multiplies) and stored as 64-byte row pieces.
+//
+// kv4_project() is the device function; kv4_kernel is it as a stand-alone launch on fp32 tokens (block 0, and every block while
+// the FFN runs its small-launch split variant); ffn_kernel<.., KV4> calls it from its epilogue on the tile it has just
+// normalised, so that the next block's keys / values leave the FFN launch directly (finished in round 4).
+struct Kv4Args {
+    const float* x;              // stand-alone kernel only: [M][128] fp32 tokens
+    const unsigned short* w;     // planes [NS][256][256] of Wc, pre-scaled by 2^wshift
+    long w_plane_stride;
+    unsigned short* out;         // planes [NS][4][M][128]
+    long out_plane_stride;       // 4 * M * 128
+    int M;
+    float out_scale;             // 2^-wshift
+};
+
+template <int NS>
+struct Kv4Lds {
+    static constexpr int RING = 2 * FfnLds<NS>::W1S;             // the W1 ring of the FFN: [0, 64 KB)
+    static constexpr int SCRP = 2048;                            // one plane of one 32 x 32 fp16 tile: 32 rows x 64 B
+    static constexpr int SCRW = 2 * NS * SCRP;                   // per wave: two parities x NS planes
+    static constexpr int SCR_BYTES = 8 * SCRW;                   // 64 KB at NS = 2
+};
+
+// yf: this wave's token operand, B fragments (k = 16 ks + 8 half + 0..7) of planes hi (| lo).  `ring` and `scr` are LDS regions no
+// other code touches during the call (ring: Kv4Lds::RING bytes, scr: SCR_BYTES); every wave of the 512-thread workgroup calls it.
+// `first_landed`: chunk 0 was already requested by the caller (dma of chunk 0 into slot 0) -- the fused epilogue issues it early.
+template <typename T, int NS, bool CHUNK0_ISSUED>
+__device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* scr, const Kv4Args& k, const i16x8 (&yf)[NS][8],
+                                            int m0, int wave, int lane, const int (&aoff)[8], float neg1) {
+    using L = FfnLds<NS>;
+    const int pair = wave & 3, role = wave >> 2;
+    const int half = lane >> 5, tl = lane & 31;
+    auto dma = [&](int c, int slot) {                            // as dma_w1: one instruction moves two ring rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 8 * i + wave;
+            const int r = 2 * blk + half, cc = tl ^ r;
+            const unsigned off = (unsigned)((((long)(32 * c + r)) * 256 + 8 * cc) * 2);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                ffn_dma16(k.w + pl * k.w_plane_stride, off, ring + slot * L::W1S + pl * L::W1P + blk * 1024);
+        }
+    };
+    unsigned char* myscr = scr + wave * Kv4Lds<NS>::SCRW;
+    const int sw = (tl >> 2) & 3;                                // scratch swizzle of this lane's token row
+    // global store of one finished chunk from the scratch: lane = (row 16 it + lane / 4, 16-byte piece lane % 4)
+    auto store_chunk = [&](int c) {
+        const unsigned char* sp = myscr + (c & 1) * (NS * Kv4Lds<NS>::SCRP);
+        const int j = 2 * role + (c >> 2);                       // which projection
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = 16 * it + (lane >> 2), q = lane & 3;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(sp + pl * Kv4Lds<NS>::SCRP + row * 64 + ((q ^ ((row >> 2) & 3)) << 4));
+                const long tok = (long)m0 + 32 * pair + row;
+                if (tok < k.M)
+                    *reinterpret_cast<u32x4*>(k.out + pl * k.out_plane_stride + ((long)j * k.M + tok) * 128 + 32 * (c & 3) + 8 * q) = d;
+            }
+    };
+    if (!CHUNK0_ISSUED) dma(0, 0);
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        const int slot = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's pieces of chunk c (requested one chunk ago) + old stores
+        __syncthreads();                                           // chunk c visible; everybody is done with chunk c - 1's slot
+        if (c + 1 < 8) dma(c + 1, slot ^ 1);
+        if (c > 0) store_chunk(c - 1);
+        const unsigned char* w1s = ring + slot * L::W1S;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            i16x8 fh[3], fl[3];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
+                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
+                }
+                if (NS == 2) {
+                    acc = T::mfma(fl[ks % 3], yf[0][ks], acc);
+                    acc = T::mfma(fh[ks % 3], yf[NS - 1][ks], acc);
+                }
+                acc = T::mfma(fh[ks % 3], yf[0][ks], acc);
+            }
+            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // accumulator rows (ring rows, = output columns 32 (c & 3) + 8 g + 4 half + i of projection j) -> fp16 hi | lo, token-major
+        unsigned char* dp = myscr + slot * (NS * Kv4Lds<NS>::SCRP) + tl * 64 + 8 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v0 = acc[4 * g] * k.out_scale, v1 = acc[4 * g + 1] * k.out_scale, v2 = acc[4 * g + 2] * k.out_scale,
+                        v3 = acc[4 * g + 3] * k.out_scale;
+            const unsigned h0 = T::pack2(v0, v1), h1 = T::pack2(v2, v3);
+            *reinterpret_cast<u32x2*>(dp + ((g ^ sw) << 4)) = u32x2{h0, h1};
+            if (NS == 2) {
+                const unsigned l0 = T::lo2(v0, v1, h0, neg1), l1 = T::lo2(v2, v3, h1, neg1);
+                *reinterpret_cast<u32x2*>(dp + Kv4Lds<NS>::SCRP + ((g ^ sw) << 4)) = u32x2{l0, l1};
+            }
+        }
+    }
+    store_chunk(7);
+}
+
+template <typename T, int NS>
+__global__ __launch_bounds__(512, 2) void kv4_kernel(Kv4Args k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float neg1 = um_opaque_neg1();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, role = wave >> 2;
+    const int half = lane >> 5, tl = lane & 31;
+    const int m0 = (int)blockIdx.x * 128;
+    const int tok = m0 + 32 * pair + tl;
+    i16x8 yf[NS][8];
+    {
+        const float* src = k.x + (long)min(tok, k.M - 1) * 128 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
+            yf[0][ks] = __builtin_bit_cast(i16x8, h);
+            if (NS == 2) {
+                const u32x4 l = {T::lo2(v0[0], v0[1], h[0], neg1), T::lo2(v0[2], v0[3], h[1], neg1),
+                                 T::lo2(v1[0], v1[1], h[2], neg1), T::lo2(v1[2], v1[3], h[3], neg1)};
+                yf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
+            }
+        }
+    }
+    const int arow = tl ^ (16 * role);
+    int aoff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) aoff[ks] = arow * 512 + (((16 * role + 2 * ks + half) ^ arow) << 4);
+    kv4_project<T, NS, false>(lds, lds + Kv4Lds<NS>::RING, k, yf, m0, wave, lane, aoff, neg1);
+}
+
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
 #ifdef UM_FFN_TRACE
@@ -892,6 +1058,51 @@ extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_plan
     const hipError_t e = mode == 0 ? launch_ffn<Fp16, 2>(a, (hipStream_t)stream_) : launch_ffn<Bf16, 1>(a, (hipStream_t)stream_);
     if (e != hipSuccess) {
         um_set_error("um_ffn_fwd: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ---- stand-alone k | v projection of a Transformer block (see kv4_project): x fp32 [m][128], wc_planes = planes of the packed
+// [256][256] weight (um_weight_planes), out_planes [NS][4][m][128]
+extern "C" int um_kv4_fwd(const float* x, const void* wc_planes, int m, int wshift, void* out_planes, int mode, void* stream_) {
+    if (!x || !wc_planes || !out_planes || m <= 0 || (mode != 0 && mode != 1) || wshift < 0 || wshift > 14) {
+        um_set_error("um_kv4_fwd: bad argument (m=%d wshift=%d mode=%d)", m, wshift, mode);
+        return -1;
+    }
+    Kv4Args k;
+    k.x = x;
+    k.w = (const unsigned short*)wc_planes;
+    k.w_plane_stride = 256L * 256;
+    k.out = (unsigned short*)out_planes;
+    k.out_plane_stride = 4L * m * 128;
+    k.M = m;
+    k.out_scale = ldexpf(1.f, -wshift);
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipSuccess;
+    ScopedKernelTimer timer(UM_K_LINEAR, stream);
+    if (mode == 0) {
+        constexpr int LDS = Kv4Lds<2>::RING + Kv4Lds<2>::SCR_BYTES;
+        static bool configured = false;
+        if (!configured) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kv4_kernel<Fp16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        hipLaunchKernelGGL((kv4_kernel<Fp16, 2>), dim3((m + 127) / 128), dim3(512), LDS, stream, k);
+    } else {
+        constexpr int LDS = Kv4Lds<1>::RING + Kv4Lds<1>::SCR_BYTES;
+        static bool configured = false;
+        if (!configured) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kv4_kernel<Bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        hipLaunchKernelGGL((kv4_kernel<Bf16, 1>), dim3((m + 127) / 128), dim3(512), LDS, stream, k);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        um_set_error("um_kv4_fwd: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
     return 0;

@@ -111,8 +111,8 @@ class TransformerLayer(nn.Module):
     def forward(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None):
         """``kv_rotate = r`` (fused path only): ``target`` holds the streams in the SAME order as ``source`` and stream ``s``
         attends the keys / values of stream ``(s + r) mod S`` -- the swapped copy ``[f1; f0]`` is never built.
-        ``kv = (planes, rows, cols, k_offset, v_offset)``: the layer's key / value projections of ``target`` already exist as
-        operand planes (the block projects both layers' k | v in one launch, or the previous block's FFN epilogue wrote them)."""
+        ``kv = (k_operand, v_operand)``: the layer's key / value projections of ``target`` already exist as operand planes
+        (``ops.kv4_slices``: the block projects both layers' k | v in one launch, or the previous block's FFN epilogue wrote them)."""
         if getattr(ops, 'fused_tail', False):
             return self._forward_fused(ops, source, target, h, w, geom, kv_rotate, kv)
         assert kv_rotate == 0 and kv is None
@@ -134,11 +134,12 @@ class TransformerLayer(nn.Module):
             if kv is None:
                 kvp, _, n2 = ops.linear_planes(target.reshape(m, c), (self.k_proj.weight, self.v_proj.weight))
                 koff, voff = 0, c
+                kop, vop = (kvp, m, n2, koff), (kvp, m, n2, voff)
             else:
-                kvp, rows, n2, koff, voff = kv
-                assert rows == m
+                kop, vop = kv                                   # attention operands prepared by the block (ops.kv4_slices)
+                assert kop[1] == m
             res = src if self.no_ffn else None
-            msg = ops.window_attention_qproj_merge(src, self.q_proj.weight, (kvp, m, n2, koff), (kvp, m, n2, voff), s, h, w, *geom,
+            msg = ops.window_attention_qproj_merge(src, self.q_proj.weight, kop, vop, s, h, w, *geom,
                                                    kv_rotate, self.merge.weight, self.norm1, res)
             if self.no_ffn:
                 return msg
@@ -203,7 +204,8 @@ class FeatureTransformer(nn.Module):
         prev = stream if rotate else torch.cat([stream[b:], stream[:b]], 0)
         # both layers of a block read their keys / values from the stream AS IT ENTERS the block (self: the stream itself; cross:
         # its halves rotated), so the four projections Wk_self | Wv_self | Wk_cross | Wv_cross are ONE launch that reads the
-        # stream once (round 4; was two launches of two projections each: transformer.py:58-60 per layer)
+        # stream once and writes blocked operand planes [NS][4][M][128] (um_kv4_fwd; round 4 -- was two um_linear_fwd launches of
+        # two projections each: transformer.py:58-60 per layer)
         block_kv = rotate and getattr(ops, 'fused_qproj', False) and getattr(ops, 'fused_merge', False) and getattr(ops, 'block_kv', True)
         s2, l, c = stream.shape
         for i, blk in enumerate(self.layers):
@@ -213,9 +215,8 @@ class FeatureTransformer(nn.Module):
             kv_s = kv_c = None
             if block_kv:
                 sa, ca = blk.self_attn, blk.cross_attn_ffn
-                kv4, m, n4 = ops.linear_planes(stream.reshape(s2 * l, c), (sa.k_proj.weight, sa.v_proj.weight,
-                                                                         ca.k_proj.weight, ca.v_proj.weight))
-                kv_s, kv_c = (kv4, m, n4, 0, c), (kv4, m, n4, 2 * c, 3 * c)
+                kv4 = ops.kv4_planes(stream.reshape(s2 * l, c), (sa.k_proj.weight, sa.v_proj.weight, ca.k_proj.weight, ca.v_proj.weight))
+                kv_s, kv_c = ops.kv4_slices(kv4, s2 * l)
             stream = blk.self_attn(ops, stream, stream, h, w, g_self, kv=kv_s)
             if rotate:                                 # keys / values come from the stream as it was before this block
                 stream, prev = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b, kv=kv_c), None

@@ -61,7 +61,7 @@ class HipOps:
     fused_ffn = True           # ... and the FFN as one kernel (um_ffn_fwd) instead of two um_linear_fwd launches
     fused_merge = True         # merge + LayerNorm (+ residual) in the attention kernel's epilogue
     fused_qproj = True         # ... and the query projection in its prologue (um_window_attn_qproj_merge_fwd)
-    block_kv = True            # one k | v projection launch per Transformer block (both layers' keys / values, N = 512)
+    block_kv = True            # one k | v projection launch per Transformer block (both layers' keys / values: um_kv4_fwd)
     # (class attributes: tests and tools/ab_bench.py flip them programmatically; the product reads no environment variable)
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
@@ -304,7 +304,12 @@ class HipOps:
                                      merge_weight, norm, residual=None):
         """:meth:`window_attention_merge` with ``q = x . Wq^T`` computed in the kernel's prologue
         (``um_window_attn_qproj_merge_fwd``): ``x`` fp32 ``[streams*h*w, 128]`` source tokens, ``q_weight`` ``[128, 128]``."""
-        (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = k, v
+        # k, v: (plane tensor, rows, row stride in elements, element offset of the first row[, plane stride in elements]) -- the
+        # optional fifth entry describes slices of a bigger plane tensor (the blocked [NS][4][M][128] k | v planes of kv4_planes)
+        (kt, krows, kcols, koff), (vt, vrows, vcols, voff) = k[:4], v[:4]
+        kps = k[4] if len(k) > 4 else krows * kcols
+        if (v[4] if len(v) > 4 else vrows * vcols) != kps:
+            raise ValueError('k and v must share their plane stride')
         self._check_rows('x', x, 128)
         if (krows, kcols) != (vrows, vcols) or x.shape[0] != streams * h * w or krows != x.shape[0]:
             raise ValueError('inconsistent plane shapes')
@@ -320,9 +325,46 @@ class HipOps:
         code = self._launch('window_attn', lambda: self.lib.um_window_attn_qproj_merge_fwd(
             _ptr(x), _ptr(wqp), _ptr(kt) + 2 * koff, _ptr(vt) + 2 * voff, _ptr(wp), _ptr(norm.weight), _ptr(norm.bias),
             _ptr(residual) if residual is not None else None, float(norm.eps), self.WSHIFT, _ptr(out), streams, h, w, 128,
-            kcols, krows * kcols, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode,
+            kcols, kps, win_h, win_w, shift_h, shift_w, kv_rotate, self.mode,
             _ptr(ks) if ks is not None else None, ks.numel() if ks is not None else 0, _stream()), meta)
         _abi.check(code, 'um_window_attn_qproj_merge_fwd')
+        return out
+
+    # ------------------------------------------------------------------ k | v projections of a whole Transformer block
+    def kv4_weight_planes(self, weights):
+        """Planes of the packed ``[256, 256]`` weight of ``um_kv4_fwd`` / ``um_ffn_kv_fwd`` from the four ``[128, 128]`` projection
+        weights (k_self, v_self, k_cross, v_cross): ``Wc[32c + r, :128] = W4[32c + r]``, ``Wc[32c + r, 128:] = W4[256 + 32c + (r ^ 16)]``
+        (include/unimatch_hip.h, um_kv4_fwd); cached until a weight changes."""
+        key, hit = self._cache_get('kv4', weights)
+        if hit is not None:
+            return hit
+        if len(weights) != 4 or any(tuple(w.shape) != (128, 128) for w in weights):
+            raise ValueError('kv4_weight_planes: expected four [128, 128] weights (k_self, v_self, k_cross, v_cross)')
+        w4 = torch.cat([w.detach().float() for w in weights], 0)                     # [512, 128]
+        perm = torch.arange(32, device=w4.device) ^ 16
+        cross = w4[256:].view(8, 32, 128)[:, perm].reshape(256, 128)
+        wc = torch.cat([w4[:256], cross], 1).contiguous()                            # [256, 256]
+        self._check_weight_range(wc, self.WSHIFT if self.mode == 0 else 0, 'Linear weight')
+        planes = torch.empty(self.lib.um_planes_bytes(256, 256, self.mode), dtype=torch.uint8, device=wc.device)
+        _abi.check(self.lib.um_weight_planes(_ptr(wc), _ptr(planes), 256, 256, self.WSHIFT, self.mode, _stream()), 'um_weight_planes')
+        return self._cache_put(key, weights, planes)
+
+    @staticmethod
+    def kv4_slices(kv, m):
+        """The four projections of blocked k | v planes ``[NS][4][m][128]`` as attention operands: ``((k_self, v_self), (k_cross, v_cross))``."""
+        part = lambda j: (kv, m, 128, j * m * 128, 4 * m * 128)
+        return (part(0), part(1)), (part(2), part(3))
+
+    def kv4_planes(self, x, weights):
+        """``um_kv4_fwd``: both layers' key / value projections of a Transformer block (four bias-free 128 x 128 Linears of the
+        token stream ``x`` fp32 ``[M, 128]``, transformer.py:58-60) in one launch -> blocked operand planes ``[NS][4][M][128]``."""
+        self._check_rows('x', x, 128)
+        wc = self.kv4_weight_planes(weights)
+        m = x.shape[0]
+        out = torch.empty(self.lib.um_planes_bytes(4 * m, 128, self.mode), dtype=torch.uint8, device=x.device)
+        code = self._launch('linear', lambda: self.lib.um_kv4_fwd(_ptr(x), _ptr(wc), m, self.WSHIFT, _ptr(out), self.mode, _stream()),
+                            {'flops': 2.0 * m * 512 * 128})
+        _abi.check(code, 'um_kv4_fwd')
         return out
 
     # ------------------------------------------------------------------ convex upsampling (SURVEY 8(f) "next" row)
