@@ -226,6 +226,13 @@ int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const v
  *     Wc[32 c + r][0:128] = W4[32 c + r][:],   Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)][:],   c = 0..7, r = 0..31,
  * W4 = the four weights stacked [512][128] (unimatch_amd/ops.py::kv4_weight_planes builds it). */
 int um_kv4_fwd(const float* x, const void* wc_planes, int m, int wshift, void* out_planes, int mode, void* stream);
+/* um_ffn_ws_fwd of block i AND um_kv4_fwd of block i + 1 on its result, from ONE launch (closed in round 4):
+ * every workgroup hands the 128-token tile it has just normalised to the k | v projection in its epilogue, so the next block's
+ * keys / values (kv_planes, blocked [NS][4][m][128]) leave the FFN kernel directly and `out` is not read back.  Launches small
+ * enough for the hidden split (um_ffn_split_workspace_bytes > 0) run the two kernels back to back inside the call. */
+int um_ffn_kv_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden, int wshift,
+                  const float* gamma, const float* beta, float eps, float* out, const void* wc_planes, void* kv_planes, int mode,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolutions either side of the matching path, NHWC, on the matrix cores with the same

@@ -1021,6 +1021,49 @@ def test_fused_layer_matches_unfused_layer(ops, golden):
         per_layer.block_kv = False
         p0, p1 = proto(per_layer, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
         assert err(p0, o0)[0] < 5e-5 and err(p0, o0)[1] < 2e-6 and err(p1, o1)[1] < 2e-6, (tag, err(p0, o0), err(p1, o1))
+        # ... and as the previous block's FFN epilogue (um_ffn_kv_fwd, the default) against the stand-alone launch per block: bitwise
+        standalone = HipOps('exact')
+        standalone.fused_kv = False
+        s0, s1 = proto(standalone, _to_tokens(f0.to(DEV)), _to_tokens(f1.to(DEV)), h, w, attn_type, k)
+        assert torch.equal(s0, o0) and torch.equal(s1, o1), tag
+
+
+@pytest.mark.parametrize('m', [1000, 313 * 128, 313 * 128 + 40])
+def test_ffn_with_the_next_blocks_kv_projection(m):
+    """um_ffn_kv_fwd: the FFN of block i and the k | v projections of block i + 1 from one launch (the normalised tile goes from the
+    LayerNorm straight into kv4_project) -- BITWISE equal to um_ffn_ws_fwd followed by um_kv4_fwd on its result (same fp32 values,
+    same hi | lo split, same chunk and product order), in both operand precisions; m = 1000 takes the hidden-split FFN + a second
+    launch inside the call, the others the fused tile kernel (census), the last with a partly empty tile."""
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    c = 128
+    x, y = rnd(1400, m, c, scale=1.5).to(DEV), rnd(1401, m, c, scale=1.5).to(DEV)
+    w1, w2 = rnd(1402, 1024, 256, scale=0.08).to(DEV), rnd(1403, 128, 1024, scale=0.06).to(DEV)
+    ws = tuple(rnd(1410 + i, 128, 128, scale=0.09).to(DEV) for i in range(4))
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.1 * rnd(1404, c).to(DEV))
+        norm.bias.copy_(0.1 * rnd(1405, c).to(DEV))
+    for prec in ('exact', 'fast'):
+        o = HipOps(prec)
+        want = o.ffn_ln(x, y, w1, w2, norm)
+        want_kv = o.kv4_planes(want, ws)
+        lib.um_census_enable(1)
+        got, kv = o.ffn_ln_kv(x, y, w1, w2, norm, ws)
+        census = _abi.census(lib)
+        lib.um_census_enable(0)
+        assert (census['ffn_hsplit'] == 1) == (m == 1000) and census['ffn_tile'] + census['ffn_hsplit'] == 1, census
+        assert torch.equal(got, want), (prec, err(got, want))
+        assert torch.equal(kv, want_kv), prec
+    # and against fp64 (exact mode): LayerNorm(W2 gelu(W1 [x | y])) + x, then the four projections
+    o = HipOps('exact')
+    got, kv = o.ffn_ln_kv(x, y, w1, w2, norm, ws)
+    hid = torch.nn.functional.gelu(torch.cat([x, y], 1).double() @ w1.double().t())
+    t64 = torch.nn.functional.layer_norm(hid @ w2.double().t(), (c,), norm.weight.double(), norm.bias.double(), norm.eps) + x.double()
+    assert err(got, t64)[1] < 2e-6
+    planes = kv.view(torch.float16).view(2, 4, m, 128).double().sum(0)
+    for j in range(4):
+        assert err(planes[j], t64 @ ws[j].double().t())[1] < 4e-6, j
 
 
 @pytest.mark.parametrize('m', [128, 1000, 2 * 6144 + 40])

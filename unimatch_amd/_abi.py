@@ -41,6 +41,8 @@ SIGNATURES = {
     'um_ffn_ws_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_size_t,
                                 _c_void_p]),
     'um_ffn_split_workspace_bytes': (_c_size_t, [_c_int] * 2),
+    'um_ffn_kv_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 2 + [ctypes.c_float, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                _c_size_t, _c_void_p]),
     'um_kv4_fwd': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p]),
     'um_conv2d_fwd': (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_void_p]),
     'um_conv2d_ex': (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p,

@@ -42,6 +42,16 @@ __device__ unsigned long long* g_um_ffn_trace = nullptr;
 #define UM_FSTAMP(slot) do { } while (0)
 #endif
 
+struct Kv4Args {
+    const float* x;              // stand-alone kernel only: [M][128] fp32 tokens
+    const unsigned short* w;     // planes [NS][256][256] of Wc, pre-scaled by 2^wshift
+    long w_plane_stride;
+    unsigned short* out;         // planes [NS][4][M][128]
+    long out_plane_stride;       // 4 * M * 128
+    int M;
+    float out_scale;             // 2^-wshift
+};
+
 struct FfnArgs {
     const float* x;               // [M, 128] source; also the residual
     const float* y;               // [M, 128] message
@@ -59,6 +69,8 @@ struct FfnArgs {
     int split;
     float* hs_part;               // [tiles][split][16][256][4] fp32: every part's partial O^T (already scaled)
     unsigned* hs_flag;            // [tiles] arrival counters, zero between launches
+    // KV4 variant: the NEXT block's key / value projections of the tile this workgroup has just finished (kv4_project)
+    Kv4Args kv;
 };
 
 __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -153,7 +165,164 @@ struct FfnLds {
     static constexpr int TOTAL = RING > 65536 ? RING : 65536;    // the epilogue overlays 4 x 16 KB of partial O
 };
 
-template <typename T, int NS, bool HSPLIT = false>
+// =================================================================================================================
+// k | v projections of BOTH layers of a Transformer block in one pass (unimatch/transformer.py:58-60, four bias-free
+// 128 x 128 Linears on the token stream as it enters the block):  out[j] = X . W_j^T,  j = k_self, v_self, k_cross, v_cross,
+// written as the attention kernel's operand planes in BLOCKED form [NS][4][M][128] (every projection its own [M][128] tensor:
+// rows of one projection are contiguous, which the attention kernel's LDS-DMA staging streams ~2 % faster than 256-byte
+// pieces of 1 KB rows).
+//
+// Same machinery as the FFN's first GEMM ("phase A"): workgroup = 8 waves = 128 tokens, wave (pair, role) owns the 32 tokens of
+// its pair; role 0 produces k_self | v_self, role 1 k_cross | v_cross.  The token operand Y^T (all 128 features, hi | lo) stays in
+// registers as B fragments for the whole pass; the 512 weight rows stream through the W1 ring in 8 chunks of (32 rows of role 0's
+// half | 32 rows of role 1's half) laid out exactly like a W1 slice -- so the host packs the four weights as one [256][256]
+// matrix  Wc[32 c + r][0:128] = W4[32 c + r],  Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)]  (role 1 reads ring rows
+// permuted by ^16, see phase A) -- one barrier per chunk, LDS-DMA one chunk ahead.  Each 32 x 32 result tile is converted to
+// fp16 hi | lo, transposed through a wave-private LDS scratch (double-buffered: the global stores of chunk c leave while chunk
+// c + 1 multiplies) and stored as 64-byte row pieces.
+//
+// kv4_project() is the device function; kv4_kernel is it as a stand-alone launch on fp32 tokens (block 0, and every block while
+// the FFN runs its small-launch split variant); ffn_kernel<.., KV4> calls it from its epilogue on the tile it has just
+// normalised, so that the next block's keys / values leave the FFN launch directly (SURVEY.md 8(f) rank 1, finished in round 4).
+
+template <int NS>
+struct Kv4Lds {
+    static constexpr int RING = 2 * FfnLds<NS>::W1S;             // the W1 ring of the FFN: [0, 64 KB)
+    static constexpr int SCRP = 2048;                            // one plane of one 32 x 32 fp16 tile: 32 rows x 64 B
+    static constexpr int SCRW = 2 * NS * SCRP;                   // per wave: two parities x NS planes
+    static constexpr int SCR_BYTES = 8 * SCRW;                   // 64 KB at NS = 2
+};
+
+// yf: this wave's token operand, B fragments (k = 16 ks + 8 half + 0..7) of planes hi (| lo).  `ring` and `scr` are LDS regions no
+// other code touches during the call (ring: Kv4Lds::RING bytes, scr: SCR_BYTES); every wave of the 512-thread workgroup calls it.
+// `first_landed`: chunk 0 was already requested by the caller (dma of chunk 0 into slot 0) -- the fused epilogue issues it early.
+template <typename T, int NS, bool CHUNK0_ISSUED>
+__device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* scr, const Kv4Args& k, const i16x8 (&yf)[NS][8],
+                                            int m0, int wave, int lane, const int (&aoff)[8], float neg1) {
+    using L = FfnLds<NS>;
+    const int pair = wave & 3, role = wave >> 2;
+    const int half = lane >> 5, tl = lane & 31;
+    auto dma = [&](int c, int slot) {                            // as dma_w1: one instruction moves two ring rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 8 * i + wave;
+            const int r = 2 * blk + half, cc = tl ^ r;
+            const unsigned off = (unsigned)((((long)(32 * c + r)) * 256 + 8 * cc) * 2);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                ffn_dma16(k.w + pl * k.w_plane_stride, off, ring + slot * L::W1S + pl * L::W1P + blk * 1024);
+        }
+    };
+    unsigned char* myscr = scr + wave * Kv4Lds<NS>::SCRW;
+    const int sw = (tl >> 2) & 3;                                // scratch swizzle of this lane's token row
+    // global store of one finished chunk from the scratch: lane = (row 16 it + lane / 4, 16-byte piece lane % 4)
+    auto store_chunk = [&](int c) {
+        const unsigned char* sp = myscr + (c & 1) * (NS * Kv4Lds<NS>::SCRP);
+        const int j = 2 * role + (c >> 2);                       // which projection
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = 16 * it + (lane >> 2), q = lane & 3;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(sp + pl * Kv4Lds<NS>::SCRP + row * 64 + ((q ^ ((row >> 2) & 3)) << 4));
+                const long tok = (long)m0 + 32 * pair + row;
+                if (tok < k.M)
+                    *reinterpret_cast<u32x4*>(k.out + pl * k.out_plane_stride + ((long)j * k.M + tok) * 128 + 32 * (c & 3) + 8 * q) = d;
+            }
+    };
+    if (!CHUNK0_ISSUED) dma(0, 0);
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        const int slot = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's pieces of chunk c (requested one chunk ago) + old stores
+        __syncthreads();                                           // chunk c visible; everybody is done with chunk c - 1's slot
+        if (c + 1 < 8) dma(c + 1, slot ^ 1);
+        if (c > 0) store_chunk(c - 1);
+        const unsigned char* w1s = ring + slot * L::W1S;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            i16x8 fh[3], fl[3];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
+                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 2 < 8) {
+                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
+                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
+                }
+                if (NS == 2) {
+                    acc = T::mfma(fl[ks % 3], yf[0][ks], acc);
+                    acc = T::mfma(fh[ks % 3], yf[NS - 1][ks], acc);
+                }
+                acc = T::mfma(fh[ks % 3], yf[0][ks], acc);
+            }
+            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // accumulator rows (ring rows, = output columns 32 (c & 3) + 8 g + 4 half + i of projection j) -> fp16 hi | lo, token-major
+        unsigned char* dp = myscr + slot * (NS * Kv4Lds<NS>::SCRP) + tl * 64 + 8 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v0 = acc[4 * g] * k.out_scale, v1 = acc[4 * g + 1] * k.out_scale, v2 = acc[4 * g + 2] * k.out_scale,
+                        v3 = acc[4 * g + 3] * k.out_scale;
+            const unsigned h0 = T::pack2(v0, v1), h1 = T::pack2(v2, v3);
+            *reinterpret_cast<u32x2*>(dp + ((g ^ sw) << 4)) = u32x2{h0, h1};
+            if (NS == 2) {
+                const unsigned l0 = T::lo2(v0, v1, h0, neg1), l1 = T::lo2(v2, v3, h1, neg1);
+                *reinterpret_cast<u32x2*>(dp + Kv4Lds<NS>::SCRP + ((g ^ sw) << 4)) = u32x2{l0, l1};
+            }
+        }
+    }
+    store_chunk(7);
+}
+
+template <typename T, int NS>
+__global__ __launch_bounds__(512, 2) void kv4_kernel(Kv4Args k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float neg1 = um_opaque_neg1();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, role = wave >> 2;
+    const int half = lane >> 5, tl = lane & 31;
+    const int m0 = (int)blockIdx.x * 128;
+    const int tok = m0 + 32 * pair + tl;
+    i16x8 yf[NS][8];
+    {
+        const float* src = k.x + (long)min(tok, k.M - 1) * 128 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
+            yf[0][ks] = __builtin_bit_cast(i16x8, h);
+            if (NS == 2) {
+                const u32x4 l = {T::lo2(v0[0], v0[1], h[0], neg1), T::lo2(v0[2], v0[3], h[1], neg1),
+                                 T::lo2(v1[0], v1[1], h[2], neg1), T::lo2(v1[2], v1[3], h[3], neg1)};
+                yf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
+            }
+        }
+    }
+    const int arow = tl ^ (16 * role);
+    int aoff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) aoff[ks] = arow * 512 + (((16 * role + 2 * ks + half) ^ arow) << 4);
+    kv4_project<T, NS, false>(lds, lds + Kv4Lds<NS>::RING, k, yf, m0, wave, lane, aoff, neg1);
+}
+
+template <typename T, int NS, bool HSPLIT = false, bool KV4 = false>
 __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     using L = FfnLds<NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -691,7 +860,21 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 #endif
     // ---- epilogue: add the partner's partial O, LayerNorm over the 128 outputs, residual ------------------------------
     __syncthreads();                                               // every ring slot and exchange buffer is dead
-    unsigned char* ob = lds + pair * 16384 + lane * 16;
+    static_assert(!(KV4 && HSPLIT), "the k | v epilogue runs on whole tiles only");
+    // KV4: the W1 ring [0, 64 KB) takes the packed k | v weight chunks (chunk 0 is requested now and lands under the LayerNorm);
+    // the exchanges and later the transposition scratch live in [64 KB, 128 KB)
+    if constexpr (KV4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 8 * i + wave;
+            const int r = 2 * blk + half, cc = tl ^ r;
+            const unsigned off = (unsigned)((((long)r) * 256 + 8 * cc) * 2);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                ffn_dma16(a.kv.w + pl * a.kv.w_plane_stride, off, lds + pl * L::W1P + blk * 1024);
+        }
+    }
+    unsigned char* ob = lds + (KV4 ? 65536 : 0) + pair * 16384 + lane * 16;
     if (role == 1) {
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
@@ -701,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                     f32x4{o[ot][4 * g], o[ot][4 * g + 1], o[ot][4 * g + 2], o[ot][4 * g + 3]};
     }
     __syncthreads();
-    if (!HSPLIT && role == 1) return;
+    if (!HSPLIT && !KV4 && role == 1) return;
     if (role == 0) {
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
@@ -769,10 +952,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         }
     half_wave_pair(s2, u, v2);
     const float rstd = 1.0f / sqrtf((u + v2) * (1.0f / 128.0f) + a.eps);
-    if (tok < a.M) {
+    if (KV4 ? role == 0 : tok < a.M) {
         // lane holds, for its token, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot)
-        float* dst = a.out + (long)tok * 128 + 4 * half;
-        const float* res = a.x + (long)tok * 128 + 4 * half;
+        const int tokc = min(tok, a.M - 1);                         // (KV4: rows past M are computed on a valid row and never stored)
+        float* dst = a.out + (long)tokc * 128 + 4 * half;
+        const float* res = a.x + (long)tokc * 128 + 4 * half;
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -784,175 +968,58 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 f32x4 yv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[i] = (o[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i] + rr[i];
-                *reinterpret_cast<f32x4*>(dst + n) = yv;
+                if (tok < a.M) *reinterpret_cast<f32x4*>(dst + n) = yv;
+                if constexpr (KV4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = yv[i];
+                }
             }
     }
-}
-
-// =================================================================================================================
-// k | v projections of BOTH layers of a Transformer block in one pass (unimatch/transformer.py:58-60, four bias-free
-// 128 x 128 Linears on the token stream as it enters the block):  out[j] = X . W_j^T,  j = k_self, v_self, k_cross, v_cross,
-// written as the attention kernel's operand planes in BLOCKED form [NS][4][M][128] (every projection its own [M][128] tensor:
-// rows of one projection are contiguous, which the attention kernel's LDS-DMA staging streams ~2 % faster than 256-byte
-// pieces of 1 KB rows).
-//
-// Same machinery as the FFN's first GEMM ("phase A"): workgroup = 8 waves = 128 tokens, wave (pair, role) owns the 32 tokens of
-// its pair; role 0 produces k_self | v_self, role 1 k_cross | v_cross.  The token operand Y^T (all 128 features, hi | lo) stays in
-// registers as B fragments for the whole pass; the 512 weight rows stream through the W1 ring in 8 chunks of (32 rows of role 0's
-// half | 32 rows of role 1's half) laid out exactly like a W1 slice -- so the host packs the four weights as one [256][256]
-// matrix  Wc[32 c + r][0:128] = W4[32 c + r],  Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)]  (role 1 reads ring rows
-// permuted by ^16, see phase A) -- one barrier per chunk, LDS-DMA one chunk ahead.  Each 32 x 32 result tile is converted to
-// fp16 hi | lo, transposed through a wave-private LDS scratch (double-buffered: the global stores of chunk c leave while chunk
-// c + 1 multiplies) and stored as 64-byte row pieces.
-//
-// kv4_project() is the device function; kv4_kernel is it as a stand-alone launch on fp32 tokens (block 0, and every block while
-// the FFN runs its small-launch split variant); ffn_kernel<.., KV4> calls it from its epilogue on the tile it has just
-// normalised, so that the next block's keys / values leave the FFN launch directly (SURVEY.md 8(f) rank 1, finished in round 4).
-struct Kv4Args {
-    const float* x;              // stand-alone kernel only: [M][128] fp32 tokens
-    const unsigned short* w;     // planes [NS][256][256] of Wc, pre-scaled by 2^wshift
-    long w_plane_stride;
-    unsigned short* out;         // planes [NS][4][M][128]
-    long out_plane_stride;       // 4 * M * 128
-    int M;
-    float out_scale;             // 2^-wshift
-};
-
-template <int NS>
-struct Kv4Lds {
-    static constexpr int RING = 2 * FfnLds<NS>::W1S;             // the W1 ring of the FFN: [0, 64 KB)
-    static constexpr int SCRP = 2048;                            // one plane of one 32 x 32 fp16 tile: 32 rows x 64 B
-    static constexpr int SCRW = 2 * NS * SCRP;                   // per wave: two parities x NS planes
-    static constexpr int SCR_BYTES = 8 * SCRW;                   // 64 KB at NS = 2
-};
-
-// yf: this wave's token operand, B fragments (k = 16 ks + 8 half + 0..7) of planes hi (| lo).  `ring` and `scr` are LDS regions no
-// other code touches during the call (ring: Kv4Lds::RING bytes, scr: SCR_BYTES); every wave of the 512-thread workgroup calls it.
-// `first_landed`: chunk 0 was already requested by the caller (dma of chunk 0 into slot 0) -- the fused epilogue issues it early.
-template <typename T, int NS, bool CHUNK0_ISSUED>
-__device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* scr, const Kv4Args& k, const i16x8 (&yf)[NS][8],
-                                            int m0, int wave, int lane, const int (&aoff)[8], float neg1) {
-    using L = FfnLds<NS>;
-    const int pair = wave & 3, role = wave >> 2;
-    const int half = lane >> 5, tl = lane & 31;
-    auto dma = [&](int c, int slot) {                            // as dma_w1: one instruction moves two ring rows
+    if constexpr (KV4) {
+        // ---- the next block's k | v projections of this tile (kv4_project): Y^T operand fragments from the normalised tile exactly as
+        // the stand-alone kernel builds them from the fp32 tokens it reads back (same hi | lo split of the same fp32 values), handed to
+        // the partner wave through LDS; k-step 2 ot + kk of the operand = registers 8 kk .. 8 kk + 7 of tile ot (as Q^T in window_attn.hip)
+        i16x8 yf[NS][8];
+        unsigned char* xch = lds + 65536 + pair * 16384 + lane * 16;
+        if (role == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int blk = 8 * i + wave;
-            const int r = 2 * blk + half, cc = tl ^ r;
-            const unsigned off = (unsigned)((((long)(32 * c + r)) * 256 + 8 * cc) * 2);
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    unsigned wh[4], wl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float p0 = o[ot][8 * kk + 2 * j], p1 = o[ot][8 * kk + 2 * j + 1];
+                        wh[j] = T::pack2(p0, p1);
+                        if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
+                    }
+                    {
+                        const auto xx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
+                        const auto yy = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
+                        const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
+                        yf[0][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
+                    }
+                    if (NS == 2) {
+                        const auto xx = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
+                        const auto yy = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
+                        const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
+                        yf[NS - 1][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
+                    }
+                }
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
-                ffn_dma16(k.w + pl * k.w_plane_stride, off, ring + slot * L::W1S + pl * L::W1P + blk * 1024);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) *reinterpret_cast<i16x8*>(xch + (pl * 8 + ks) * 1024) = yf[pl][ks];
         }
-    };
-    unsigned char* myscr = scr + wave * Kv4Lds<NS>::SCRW;
-    const int sw = (tl >> 2) & 3;                                // scratch swizzle of this lane's token row
-    // global store of one finished chunk from the scratch: lane = (row 16 it + lane / 4, 16-byte piece lane % 4)
-    auto store_chunk = [&](int c) {
-        const unsigned char* sp = myscr + (c & 1) * (NS * Kv4Lds<NS>::SCRP);
-        const int j = 2 * role + (c >> 2);                       // which projection
+        __syncthreads();
+        if (role == 1) {
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
+            for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = 16 * it + (lane >> 2), q = lane & 3;
-                const u32x4 d = *reinterpret_cast<const u32x4*>(sp + pl * Kv4Lds<NS>::SCRP + row * 64 + ((q ^ ((row >> 2) & 3)) << 4));
-                const long tok = (long)m0 + 32 * pair + row;
-                if (tok < k.M)
-                    *reinterpret_cast<u32x4*>(k.out + pl * k.out_plane_stride + ((long)j * k.M + tok) * 128 + 32 * (c & 3) + 8 * q) = d;
-            }
-    };
-    if (!CHUNK0_ISSUED) dma(0, 0);
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-        const int slot = c & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's pieces of chunk c (requested one chunk ago) + old stores
-        __syncthreads();                                           // chunk c visible; everybody is done with chunk c - 1's slot
-        if (c + 1 < 8) dma(c + 1, slot ^ 1);
-        if (c > 0) store_chunk(c - 1);
-        const unsigned char* w1s = ring + slot * L::W1S;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
-            i16x8 fh[3], fl[3];
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                fh[ks] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks]);
-                if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks]);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 2 < 8) {
-                    fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + aoff[ks + 2]);
-                    if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(w1s + L::W1P + aoff[ks + 2]);
-                }
-                if (NS == 2) {
-                    acc = T::mfma(fl[ks % 3], yf[0][ks], acc);
-                    acc = T::mfma(fh[ks % 3], yf[NS - 1][ks], acc);
-                }
-                acc = T::mfma(fh[ks % 3], yf[0][ks], acc);
-            }
-            constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
-            __builtin_amdgcn_s_setprio(0);
+                for (int ks = 0; ks < 8; ++ks) yf[pl][ks] = *reinterpret_cast<const i16x8*>(xch + (pl * 8 + ks) * 1024);
         }
-        // accumulator rows (ring rows, = output columns 32 (c & 3) + 8 g + 4 half + i of projection j) -> fp16 hi | lo, token-major
-        unsigned char* dp = myscr + slot * (NS * Kv4Lds<NS>::SCRP) + tl * 64 + 8 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float v0 = acc[4 * g] * k.out_scale, v1 = acc[4 * g + 1] * k.out_scale, v2 = acc[4 * g + 2] * k.out_scale,
-                        v3 = acc[4 * g + 3] * k.out_scale;
-            const unsigned h0 = T::pack2(v0, v1), h1 = T::pack2(v2, v3);
-            *reinterpret_cast<u32x2*>(dp + ((g ^ sw) << 4)) = u32x2{h0, h1};
-            if (NS == 2) {
-                const unsigned l0 = T::lo2(v0, v1, h0, neg1), l1 = T::lo2(v2, v3, h1, neg1);
-                *reinterpret_cast<u32x2*>(dp + Kv4Lds<NS>::SCRP + ((g ^ sw) << 4)) = u32x2{l0, l1};
-            }
-        }
+        kv4_project<T, NS, true>(lds, lds + 65536, a.kv, yf, m0, wave, lane, aoff, neg1);
     }
-    store_chunk(7);
-}
-
-template <typename T, int NS>
-__global__ __launch_bounds__(512, 2) void kv4_kernel(Kv4Args k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const float neg1 = um_opaque_neg1();
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave & 3, role = wave >> 2;
-    const int half = lane >> 5, tl = lane & 31;
-    const int m0 = (int)blockIdx.x * 128;
-    const int tok = m0 + 32 * pair + tl;
-    i16x8 yf[NS][8];
-    {
-        const float* src = k.x + (long)min(tok, k.M - 1) * 128 + 8 * half;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
-            const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
-            yf[0][ks] = __builtin_bit_cast(i16x8, h);
-            if (NS == 2) {
-                const u32x4 l = {T::lo2(v0[0], v0[1], h[0], neg1), T::lo2(v0[2], v0[3], h[1], neg1),
-                                 T::lo2(v1[0], v1[1], h[2], neg1), T::lo2(v1[2], v1[3], h[3], neg1)};
-                yf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
-            }
-        }
-    }
-    const int arow = tl ^ (16 * role);
-    int aoff[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) aoff[ks] = arow * 512 + (((16 * role + 2 * ks + half) ^ arow) << 4);
-    kv4_project<T, NS, false>(lds, lds + Kv4Lds<NS>::RING, k, yf, m0, wave, lane, aoff, neg1);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -963,23 +1030,26 @@ extern "C" int um_debug_set_ffn_trace(void* ptr) {
 }
 #endif
 
-template <typename T, int NS, bool HSPLIT>
+template <typename T, int NS, bool HSPLIT, bool KV4 = false>
 static hipError_t launch_ffn_impl(const FfnArgs& a, hipStream_t stream) {
+    // KV4: ring [0, 64 KB) + exchange / scratch [64 KB, 128 KB) -- the same 128 KB the main loop uses
+    constexpr int LDS = FfnLds<NS>::TOTAL > 131072 ? FfnLds<NS>::TOTAL : (KV4 ? 131072 : FfnLds<NS>::TOTAL);
     static bool configured = false;          // opt in to > 64 KB of LDS once per instantiation
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_kernel<T, NS, HSPLIT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FfnLds<NS>::TOTAL);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_kernel<T, NS, HSPLIT, KV4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         configured = true;
     }
     ScopedKernelTimer timer(UM_K_FFN, stream);
     um_census_hit(HSPLIT ? UM_V_FFN_HSPLIT : UM_V_FFN_TILE);
-    hipLaunchKernelGGL((ffn_kernel<T, NS, HSPLIT>), dim3(((a.M + 127) / 128) * a.split), dim3(512), FfnLds<NS>::TOTAL, stream, a);
+    hipLaunchKernelGGL((ffn_kernel<T, NS, HSPLIT, KV4>), dim3(((a.M + 127) / 128) * a.split), dim3(512), LDS, stream, a);
     return hipGetLastError();
 }
 
 template <typename T, int NS>
 static hipError_t launch_ffn(const FfnArgs& a, hipStream_t stream) {
+    if (a.kv.w) return launch_ffn_impl<T, NS, false, true>(a, stream);       // (callers only set kv on un-split launches)
     return a.split > 1 ? launch_ffn_impl<T, NS, true>(a, stream) : launch_ffn_impl<T, NS, false>(a, stream);
 }
 
@@ -1016,9 +1086,35 @@ extern "C" int um_ffn_fwd(const float* x, const float* y, const void* w1_planes,
     return um_ffn_ws_fwd(x, y, w1_planes, w2_planes, m, hidden, wshift, gamma, beta, eps, out, mode, nullptr, 0, stream_);
 }
 
+extern "C" int um_kv4_fwd(const float* x, const void* wc_planes, int m, int wshift, void* out_planes, int mode, void* stream_);
+static int ffn_impl(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                    int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
+                    size_t workspace_bytes, const void* wc_planes, void* kv_planes, void* stream_);
+
 extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
                              int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
                              size_t workspace_bytes, void* stream_) {
+    return ffn_impl(x, y, w1_planes, w2_planes, m, hidden, wshift, gamma, beta, eps, out, mode, workspace, workspace_bytes, nullptr,
+                    nullptr, stream_);
+}
+
+// The FFN of block i AND the key / value projections of block i + 1 (um_kv4_fwd's result on `out`) from one launch: the tile a
+// workgroup has just normalised goes straight into kv4_project.  Small launches (hidden split, see um_ffn_split_workspace_bytes)
+// keep the FFN's split variant and run um_kv4_fwd as a second launch: same results either way, the caller need not know.
+extern "C" int um_ffn_kv_fwd(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                             int wshift, const float* gamma, const float* beta, float eps, float* out, const void* wc_planes,
+                             void* kv_planes, int mode, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!wc_planes || !kv_planes) {
+        um_set_error("um_ffn_kv_fwd: null k | v weight planes or output planes");
+        return -1;
+    }
+    return ffn_impl(x, y, w1_planes, w2_planes, m, hidden, wshift, gamma, beta, eps, out, mode, workspace, workspace_bytes, wc_planes,
+                    kv_planes, stream_);
+}
+
+static int ffn_impl(const float* x, const float* y, const void* w1_planes, const void* w2_planes, int m, int hidden,
+                    int wshift, const float* gamma, const float* beta, float eps, float* out, int mode, void* workspace,
+                    size_t workspace_bytes, const void* wc_planes, void* kv_planes, void* stream_) {
     if (!x || !y || !w1_planes || !w2_planes || !gamma || !beta || !out || m <= 0 || hidden < 64 || hidden % 32 != 0 ||
         (mode != 0 && mode != 1) || wshift < 0 || wshift > 14) {
         um_set_error("um_ffn_fwd: bad argument (m=%d hidden=%d wshift=%d mode=%d; hidden must be a multiple of 32, >= 64)",
@@ -1046,6 +1142,7 @@ extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_plan
     a.split = 1;
     a.hs_part = nullptr;
     a.hs_flag = nullptr;
+    a.kv = Kv4Args{};
     if (workspace) {
         const int split = ffn_hidden_split(m, hidden);
         if (split > 1 && workspace_bytes >= ffn_hs_bytes(m, split)) {
@@ -1055,11 +1152,23 @@ extern "C" int um_ffn_ws_fwd(const float* x, const float* y, const void* w1_plan
             a.hs_part = (float*)((unsigned char*)workspace + ((slots * sizeof(unsigned) + 255) & ~(size_t)255));
         }
     }
+    static const bool no_fuse = um_debug_env("UM_FFN_NO_KV4") != nullptr;     // A/B switch (diagnostic builds): always two launches
+    const bool fuse = wc_planes && a.split == 1 && !no_fuse;
+    if (fuse) {
+        a.kv.x = nullptr;
+        a.kv.w = (const unsigned short*)wc_planes;
+        a.kv.w_plane_stride = 256L * 256;
+        a.kv.out = (unsigned short*)kv_planes;
+        a.kv.out_plane_stride = 4L * m * 128;
+        a.kv.M = m;
+        a.kv.out_scale = a.out_scale;
+    }
     const hipError_t e = mode == 0 ? launch_ffn<Fp16, 2>(a, (hipStream_t)stream_) : launch_ffn<Bf16, 1>(a, (hipStream_t)stream_);
     if (e != hipSuccess) {
         um_set_error("um_ffn_fwd: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
+    if (wc_planes && !fuse) return um_kv4_fwd(out, wc_planes, m, wshift, kv_planes, mode, stream_);
     return 0;
 }
 

@@ -108,14 +108,14 @@ class TransformerLayer(nn.Module):
                                      nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
             self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None):
+    def forward(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None, next_kv_weights=None):
         """``kv_rotate = r`` (fused path only): ``target`` holds the streams in the SAME order as ``source`` and stream ``s``
         attends the keys / values of stream ``(s + r) mod S`` -- the swapped copy ``[f1; f0]`` is never built.
         ``kv = (k_operand, v_operand)``: the layer's key / value projections of ``target`` already exist as operand planes
         (``ops.kv4_slices``: the block projects both layers' k | v in one launch, or the previous block's FFN epilogue wrote them)."""
         if getattr(ops, 'fused_tail', False):
-            return self._forward_fused(ops, source, target, h, w, geom, kv_rotate, kv)
-        assert kv_rotate == 0 and kv is None
+            return self._forward_fused(ops, source, target, h, w, geom, kv_rotate, kv, next_kv_weights)
+        assert kv_rotate == 0 and kv is None and next_kv_weights is None
         q, k, v = self.q_proj(source), self.k_proj(target), self.v_proj(target)
         msg = ops.window_attention(q, k, v, h, w, *geom)
         msg = self.norm1(self.merge(msg))
@@ -123,7 +123,9 @@ class TransformerLayer(nn.Module):
             msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
         return source + msg
 
-    def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None):
+    def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None, next_kv_weights=None):
+        """``next_kv_weights``: the four k | v projection weights of the NEXT block -- the FFN launch then also returns that
+        block's blocked k | v planes (``ops.ffn_ln_kv``) and the result is ``(tokens, planes)``."""
         """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
         (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``)."""
         s, l, c = source.shape
@@ -144,11 +146,14 @@ class TransformerLayer(nn.Module):
             if self.no_ffn:
                 return msg
             msg = msg.reshape(m, c)
+            if next_kv_weights is not None:
+                out, nkv = ops.ffn_ln_kv(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2, next_kv_weights)
+                return out.reshape(s, l, c), nkv
             if getattr(ops, 'fused_ffn', False):
                 return ops.ffn_ln(src, msg, self.mlp[0].weight, self.mlp[2].weight, self.norm2).reshape(s, l, c)
             hid, _, nh = ops.linear_planes(src, (self.mlp[0].weight,), a1=msg, gelu=True)
             return ops.linear_ln(hid, (self.mlp[2].weight,), self.norm2, residual=src, a_planes_k=nh).reshape(s, l, c)
-        assert kv is None, 'precomputed k | v planes need the fused q-projection / merge path'
+        assert kv is None and next_kv_weights is None, 'precomputed k | v planes need the fused q-projection / merge path'
         if target is source:                       # self attention: one projection launch for q | k | v
             qkv, _, n3 = ops.linear_planes(src, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight))
             q, k, v = (qkv, m, n3, 0), (qkv, m, n3, c), (qkv, m, n3, 2 * c)
@@ -208,18 +213,27 @@ class FeatureTransformer(nn.Module):
         # two projections each: transformer.py:58-60 per layer)
         block_kv = rotate and getattr(ops, 'fused_qproj', False) and getattr(ops, 'fused_merge', False) and getattr(ops, 'block_kv', True)
         s2, l, c = stream.shape
+        # ... and from block 1 on they come out of the previous block's FFN launch (um_ffn_kv_fwd): no projection launch at all
+        fused_kv = block_kv and getattr(ops, 'fused_kv', False) and getattr(ops, 'fused_ffn', False)
+        kv4 = None
+        kvw = lambda b_: (b_.self_attn.k_proj.weight, b_.self_attn.v_proj.weight, b_.cross_attn_ffn.k_proj.weight,
+                          b_.cross_attn_ffn.v_proj.weight)
         for i, blk in enumerate(self.layers):
             shift = ('swin' in attn_type) and attn_num_splits > 1 and i % 2 == 1
             g_self = attention_windows(attn_type, True, attn_num_splits, h, w, shift)
             g_cross = attention_windows(attn_type, False, attn_num_splits, h, w, shift)
             kv_s = kv_c = None
             if block_kv:
-                sa, ca = blk.self_attn, blk.cross_attn_ffn
-                kv4 = ops.kv4_planes(stream.reshape(s2 * l, c), (sa.k_proj.weight, sa.v_proj.weight, ca.k_proj.weight, ca.v_proj.weight))
+                if kv4 is None:                        # block 0 (or fused_kv off): the stand-alone launch
+                    kv4 = ops.kv4_planes(stream.reshape(s2 * l, c), kvw(blk))
                 kv_s, kv_c = ops.kv4_slices(kv4, s2 * l)
+                kv4 = None
             stream = blk.self_attn(ops, stream, stream, h, w, g_self, kv=kv_s)
             if rotate:                                 # keys / values come from the stream as it was before this block
-                stream, prev = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b, kv=kv_c), None
+                nxt = kvw(self.layers[i + 1]) if fused_kv and i + 1 < len(self.layers) else None
+                stream = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross, kv_rotate=b, kv=kv_c, next_kv_weights=nxt)
+                if nxt is not None:
+                    stream, kv4 = stream
                 prev = stream
             else:
                 stream = blk.cross_attn_ffn(ops, stream, prev, h, w, g_cross)

@@ -62,6 +62,7 @@ class HipOps:
     fused_merge = True         # merge + LayerNorm (+ residual) in the attention kernel's epilogue
     fused_qproj = True         # ... and the query projection in its prologue (um_window_attn_qproj_merge_fwd)
     block_kv = True            # one k | v projection launch per Transformer block (both layers' keys / values: um_kv4_fwd)
+    fused_kv = True            # ... which, from block 1 on, is the previous block's FFN epilogue (um_ffn_kv_fwd): no launch at all
     # (class attributes: tests and tools/ab_bench.py flip them programmatically; the product reads no environment variable)
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
     CONV_MODE = 0              # ... always in the exact arithmetic: 'fast' (bf16) is a property of the matching path only
@@ -229,6 +230,30 @@ class HipOps:
             _stream()), {'flops': 2.0 * m * hid * (256 + 128)})
         _abi.check(code, 'um_ffn_ws_fwd')
         return out
+
+    def ffn_ln_kv(self, x, y, w1, w2, norm, kv_weights):
+        """:meth:`ffn_ln` plus the NEXT block's key / value projections of its result (:meth:`kv4_planes` of the returned tokens with
+        ``kv_weights`` = next block's (k_self, v_self, k_cross, v_cross)) from the same launch (``um_ffn_kv_fwd``; small launches
+        run the two kernels back to back inside the call) -> ``(out fp32 [M, 128], blocked k | v planes)``."""
+        w1p, hid, k1 = self.weight_planes((w1,))
+        w2p, n2, k2 = self.weight_planes((w2,))
+        if (k1, n2, k2) != (256, 128, hid):
+            raise ValueError(f'ffn_ln_kv: expected W1 [hidden, 256] and W2 [128, hidden], got {tuple(w1.shape)} {tuple(w2.shape)}')
+        self._check_rows('x', x, 128)
+        self._check_rows('y', y, 128)
+        m = x.shape[0]
+        if y.shape[0] != m:
+            raise ValueError('ffn_ln_kv: x and y must have the same number of rows')
+        wc = self.kv4_weight_planes(kv_weights)
+        out = torch.empty((m, 128), dtype=torch.float32, device=x.device)
+        kv = torch.empty(self.lib.um_planes_bytes(4 * m, 128, self.mode), dtype=torch.uint8, device=x.device)
+        ws = self._split_workspace('_ffn_ws', self.lib.um_ffn_split_workspace_bytes(m, hid), x.device)
+        code = self._launch('ffn', lambda: self.lib.um_ffn_kv_fwd(
+            _ptr(x), _ptr(y), _ptr(w1p), _ptr(w2p), m, hid, self.WSHIFT, _ptr(norm.weight), _ptr(norm.bias),
+            float(norm.eps), _ptr(out), _ptr(wc), _ptr(kv), self.mode, _ptr(ws) if ws is not None else None,
+            ws.numel() if ws is not None else 0, _stream()), {'flops': 2.0 * m * hid * (256 + 128) + 2.0 * m * 512 * 128})
+        _abi.check(code, 'um_ffn_kv_fwd')
+        return out, kv
 
     def window_attention_planes(self, q, k, v, streams, h, w, win_h, win_w, shift_h=0, shift_w=0, kv_rotate=0):
         """Attention on operand planes.  q, k, v: ``(plane_tensor, rows, cols, col_offset)`` -- a 128-column slice
