@@ -417,12 +417,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             base + (8 * wave) * 256 + (isv * NS + pl) * PLANE));
         unsigned keep;
         if (UM_WATTN_OFF32) {
+            // the second request's instruction offset (1024: its LDS displacement) also moves its SOURCE: compensated in the SCALAR
+            // base, not in the offset register -- that one is zero-extended, so "offset - 1024" of a row in the first kilobyte of
+            // the plane would address 4 GiB further on
             const unsigned short* base = (isv ? a.vp : a.kp) + pl * a.kv_plane_stride;       // wave-uniform: SGPR pair
+            const unsigned short* base1 = base - 512;
             const unsigned o0 = isv ? sov[0] : sok[0];
-            const unsigned o1 = (isv ? sov[1] : sok[1]) - 1024u;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                         "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base), "s"(dst) : "memory");
+            const unsigned o1 = isv ? sov[1] : sok[1];
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "global_load_lds_dwordx4 %2, %4 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base), "s"(base1), "s"(dst) : "memory");
             return;
         }
         const unsigned short* s0 = (isv ? spv[0] : spk[0]) + pl * a.kv_plane_stride;
