@@ -393,8 +393,19 @@ def main():
                 'frac': round(tot / PEAK_MFMA_16BIT, 4), 'issued_mfma_frac': round(tot * issued / PEAK_MFMA_16BIT, 4)}
         r2 = roofline_block('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
                             hot[1], gsv_flops, n_gsv, precision, pmc_ok)
-        r3 = roofline_block('ffn_kernel (whole Transformer FFN, one launch)', f'ffn_kernel<{tag}, false>', ['ffn.hip', 'common.h'],
-                            hot[10], ffn_flops, n_ffn, precision, pmc_ok)
+        fused_kv = all(getattr(HipOps, k_, False) for k_ in ('block_kv', 'fused_kv', 'fused_ffn', 'fused_qproj', 'fused_merge'))
+        # with fused_kv every FFN launch but the last block's also executes the NEXT block's four k | v projections (um_ffn_kv_fwd):
+        # `frac` prices what the launches execute (FFN + those projections); the FFN proper is in `ffn_only`
+        kv_flops = sum(5 * 2.0 * S * h * w * 512 * 128 for h, w, _ in scales) if fused_kv else 0.0
+        r3 = roofline_block('ffn_kernel (whole Transformer FFN' + (' + next block\'s k|v projections' if fused_kv else '') + ', one launch)',
+                            f"ffn_kernel<{tag}, false, {'true' if fused_kv else 'false'}>", ['ffn.hip', 'common.h'],
+                            hot[10], ffn_flops + kv_flops, n_ffn, precision, pmc_ok)
+        if r3 is not None:
+            dur = hot[10][0] * 1e-3 / (hot[10][1] / n_ffn)
+            r3['ffn_only'] = {'note': 'FFN FLOPs alone (transformer.py:141-144: 2 M 8C 3C per launch) over the same launch time'
+                                      + (' -- which 5 of 6 launches share with the k | v projections of the next block' if fused_kv else ''),
+                              'algorithmic_gflop_per_launch': round(ffn_flops / n_ffn / 1e9, 2),
+                              'frac': round(ffn_flops / dur / PEAK_MFMA_16BIT, 4)}
         return r1, r2, r3
 
     def sums(hot, enc, steps):

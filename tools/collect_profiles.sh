@@ -20,11 +20,11 @@ if [ -n "$TRACE" ]; then python tools/steady_state.py "$TRACE" 10 > "$OUT/${TAG}
 (cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/${TAG}_pmc -o p -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmc.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmc -name '*counter_collection.csv' | head -1)
-if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply window_attn gsv ffn_kernel linear_kernel > "$OUT/${TAG}_pmc_fetch.json"; fi
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" conv_ nhwc_apply window_attn gsv ffn_kernel linear_kernel kv4_kernel > "$OUT/${TAG}_pmc_fetch.json"; fi
 (cd /tmp && timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/${TAG}_pmcw -o p -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcw.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmcw -name '*counter_collection.csv' | head -1)
-if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv > "$OUT/${TAG}_pmc_write.json"; fi
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_kernel kv4_kernel > "$OUT/${TAG}_pmc_write.json"; fi
 (cd /tmp && timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY \
     --kernel-trace --output-format csv -d /tmp/${TAG}_pmcs -o p -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcs.log" 2>&1 < /dev/null)

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from bench import PMC_FILE, source_stamp  # noqa: E402
 
 KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv3_kernel': ['global_match.hip', 'common.h'],
-           'gsv4_kernel': ['global_match.hip', 'common.h'], 'ffn_kernel': ['ffn.hip', 'common.h']}
+           'gsv4_kernel': ['global_match.hip', 'common.h'], 'ffn_kernel': ['ffn.hip', 'common.h'], 'kv4_kernel': ['ffn.hip', 'common.h']}
 NUM_SIMDS, NUM_XCDS = 1024, 8
 
 

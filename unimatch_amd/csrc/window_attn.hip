@@ -46,6 +46,7 @@ __device__ unsigned long long* g_um_trace = nullptr;
 // Round-4 experiments on the tile loop (diagnostic builds, profiles/r04_attention_experiments.txt):
 //   UM_WATTN_DMA_POS  0: the tile's four LDS-DMA statements ride on QK^T k-steps 0, 2, 4, 6 (rounds 1-3)
 //                     1: they are issued in the softmax phase (VALU only) instead of inside an MFMA phase
+//                     2: on QK^T k-steps 1, 3, 5, 7 (the address preparation no longer stands in front of the first MFMA)
 //   UM_WATTN_OFF32    1: staging sources as 32-bit byte offsets from a scalar base (global_load_lds ... v, s[base]) instead of
 //                        64-bit per-lane pointers: half the address registers, no 64-bit arithmetic per tile
 #ifndef UM_WATTN_DMA_POS
@@ -482,6 +483,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + PLANE + koff[ks + 2]);
                 }
                 if (UM_WATTN_DMA_POS == 0 && staging && (ks * NPAIR) % 8 == 0) stage_pair(ks * NPAIR / 8, nxt);
+                if (UM_WATTN_DMA_POS == 2 && staging && NPAIR == 4 && (ks & 1)) stage_pair(ks >> 1, nxt);   // k-steps 1, 3, 5, 7
+                if (UM_WATTN_DMA_POS == 2 && staging && NPAIR == 2 && (ks == 3 || ks == 7)) stage_pair(ks >> 2, nxt);
                 if (NS == 2) {
                     sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
                     sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
