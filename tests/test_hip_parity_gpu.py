@@ -610,6 +610,10 @@ def test_fused_ffn_kernel(ops, m, hidden):
         hp_, _, nh = ops.linear_planes(xd, (w1d,), a1=yd, gelu=True)
         two = ops.linear_ln(hp_, (w2d,), norm, residual=xd, a_planes_k=nh)
         assert err(got, two)[0] < 2e-5
+    # the bf16 throughput mode runs the same main loop with one operand plane and one product (other gap counts in the software
+    # pipeline: round 4's re-ordered loop first lost the accumulator hand-over there): bf16-level agreement with fp64
+    fast = HipOps('fast').ffn_ln(xd, yd, w1d, w2d, norm)
+    assert torch.isfinite(fast).all() and err(fast, want)[1] < 2e-2 and err(fast, want)[0] < 0.5, err(fast, want)
 
 
 def test_fused_ffn_rejects_bad_arguments(ops):

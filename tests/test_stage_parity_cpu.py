@@ -9,7 +9,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-os.environ['UM_STAGE_SIZE'] = '64,96'            # before the harness import: inherited by its worker processes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -34,9 +33,21 @@ class StageOracleOps(OracleOps):
 
 @pytest.fixture(scope='module')
 def legs():
+    """Reduced frame size for the duration of THIS module only: the environment variable reaches the (spawned) worker processes,
+    the parent's copy of the size table is patched and restored -- the GPU suites import the same harness at full size."""
+    old_env, old_runs = os.environ.get('UM_STAGE_SIZE'), sp.pf.RUNS
+    os.environ['UM_STAGE_SIZE'] = '64,96'
+    sp.pf.RUNS = {c: (r[0], 64, 96, r[3]) for c, r in old_runs.items()}
     pool = sp.StageLegs(workers=2, threads=2)
-    yield pool
-    pool.close()
+    try:
+        yield pool
+    finally:
+        pool.close()
+        sp.pf.RUNS = old_runs
+        if old_env is None:
+            os.environ.pop('UM_STAGE_SIZE', None)
+        else:
+            os.environ['UM_STAGE_SIZE'] = old_env
 
 
 @pytest.mark.parametrize('cfg', [3, 4, 2])

@@ -778,16 +778,19 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                     const int bslot = m * 4 + ot;
                     dma_share(mslot);                              // (only when there was no phase A: the last slice)
                     if (decltype(has_a_tag)::value) {
-                        // hand-over of S^T(i+1): the last phase-A MFMAs retire under the first phase-B MFMAs
-                        if (bslot == 2) {
+                        // hand-over of S^T(i+1): the last phase-A MFMAs retire under the first phase-B MFMAs.  Gaps H0, H0 + 1, H0 + 2
+                        // of phase B (2, 3, 4 with three products; 1, 2, 3 when phase B has only four MFMAs: one bf16 plane)
+                        constexpr int H0 = NB >= 6 ? 2 : NB - 3;
+                        static_assert(NB == 0 || H0 >= 0, "phase B too short for the hand-over");
+                        if (bslot == H0) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) scn[r] += scm[r];
                         }
-                        if (bslot == 3) {
+                        if (bslot == H0 + 1) {
 #pragma unroll
                             for (int r = 8; r < 16; ++r) scn[r] += scm[r];
                         }
-                        if (bslot == 4) send(scn, slot ^ 1);
+                        if (bslot == H0 + 2) send(scn, slot ^ 1);
                     }
                     valu_share(mslot++);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
