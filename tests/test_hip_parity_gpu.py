@@ -456,6 +456,46 @@ def test_local_kernels_random_shapes(ops, case):
     assert err(got, want)[0] < 2e-4 * max(1.0, want.abs().max().item()), case
 
 
+@pytest.mark.parametrize('case', ['sideways', 'diagonal', 'forward', 'many_candidates', 'argmax'])
+def test_plane_sweep_box_and_gather_paths(ops, case):
+    """um_depth_corr_softmax (matching.py:203-282) through all of its paths against the fp64 oracle: the integer-neighbourhood form
+    (lane = candidate, dots with the distinct f1 rows of the candidates' bounding box, blended from a wave-private table) for a
+    sideways move; a long DIAGONAL epipolar segment whose box exceeds the table (per-pixel gather fallback inside the same kernel);
+    a forward move (epipolar lines radiate from the centre: boxes of every shape, candidates leaving the image); more than 64
+    candidates (the gather kernel); and the arg-max read-out (first index attaining the maximum)."""
+    b, h, w = 2, 30, 40
+    f0, f1 = rnd(1500, b, C, h, w), rnd(1501, b, C, h, w)
+    f1 = 0.6 * f0.roll((0, 2), (2, 3)) + 0.4 * f1
+    t0, t1 = tok(f0).to(DEV), tok(f1).to(DEV)
+    fx = 0.9 * w
+    k = torch.tensor([[fx, 0, w / 2], [0, fx, h / 2], [0, 0, 1.0]])[None].repeat(b, 1, 1)
+    pose = torch.eye(4)[None].repeat(b, 1, 1)
+    nd, argmax = 64, False
+    if case == 'sideways':
+        pose[:, :3, 3] = torch.tensor([0.12, -0.01, 0.0])
+    elif case == 'diagonal':
+        pose[:, :3, 3] = torch.tensor([0.45, 0.40, 0.0])              # ~30 x 27 cells between the first and the last candidate
+    elif case == 'forward':
+        pose[:, :3, 3] = torch.tensor([0.02, 0.01, 0.30])
+        ang = 0.04
+        pose[1, :3, :3] = torch.tensor([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1.0]])
+    elif case == 'many_candidates':
+        pose[:, :3, 3] = torch.tensor([0.12, -0.03, 0.02])
+        nd = 80
+    else:
+        pose[:, :3, 3] = torch.tensor([0.10, 0.02, 0.01])
+        argmax = True
+    cand = torch.linspace(1 / 10.0, 1 / 0.5, nd)
+    want = hp.depth_corr_softmax(f0.double(), f1.double(), k.double(), pose.double(), cand.double(), argmax)
+    cam = torch.cat([torch.inverse(k).flatten(1), pose[:, :3, :3].flatten(1), pose[:, :3, 3], k.flatten(1)], 1)
+    got = ops.depth_corr_softmax(t0, t1, h, w, cam.contiguous().to(DEV), cand.to(DEV), from_argmax=argmax)
+    assert torch.isfinite(got).all()
+    if argmax:                                                          # ties / near-ties may pick a neighbouring candidate
+        assert (got.cpu().double() - want).abs().gt(1e-6).float().mean().item() < 0.01
+    else:
+        assert err(got, want)[0] < 2e-4 * max(1.0, want.abs().max().item()), (case, err(got, want))
+
+
 def test_cost_volume_config4_size_properties(ops):
     """At config-4's scale-1 size (128x192): zero flow -> the centre tap equals the plain per-pixel
     correlation f0.f1/sqrt(C), and an integer flow only shifts which tap that is (bilinear weights 1,0,0,0)."""

@@ -389,6 +389,86 @@ __global__ __launch_bounds__(256) void prop_local_attn_kernel(const float* __res
 // cam: per sample 30 floats = Kinv[9] | R[9] | t[3] | K[9], row major.
 // The [B, C, D, h, w] warped volume of the reference (2.5 GB at B=16, 480x640) never exists.
 // ------------------------------------------------------------------------------------------------------
+// One pixel by plain gathers (the wave's lanes = 16 candidate slots x 4 channel quarters, four bilinear corners of every candidate
+// fetched from f1: 4 x 512 B per candidate).  Serves launches with more than 64 candidates and the pixels whose candidates' corner
+// set does not fit the box table of depth_corr_softmax_box_kernel.  Returns the pixel's result on every lane.
+__device__ __forceinline__ float depth_pixel_gather(const float* __restrict__ f0, const float* __restrict__ f1, const float* cm,
+                                                    const float* __restrict__ cand, long pid, int b, int h, int w, int nd,
+                                                    int from_argmax, float q0, float q1, float q2, int lane) {
+    const int slot = lane >> 2, quarter = lane & 3;
+    const int L = h * w;
+    const int rounds = (nd + 15) >> 4;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    f32x4 a[8];
+    load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
+    float logit[LOCAL_MAX_ROUNDS], cv[LOCAL_MAX_ROUNDS];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+        logit[r] = -3.0e38f;
+        cv[r] = 0.f;
+        if (r < rounds) {
+            const int t = r * 16 + slot;
+            const bool tap = t < nd;
+            const float ci = cand[tap ? t : 0];
+            cv[r] = ci;
+            const float depth = 1.0f / ci;
+            const float X = q0 * depth + cm[18], Y = q1 * depth + cm[19], Z = q2 * depth + cm[20];
+            const float u = cm[21] * X + cm[22] * Y + cm[23] * Z;
+            const float v = cm[24] * X + cm[25] * Y + cm[26] * Z;
+            const float zz = fmaxf(cm[27] * X + cm[28] * Y + cm[29] * Z, 1e-3f);
+            const float sx = fminf(fmaxf(u / zz, -1.0e6f), 1.0e6f);
+            const float sy = fminf(fmaxf(v / zz, -1.0e6f), 1.0e6f);
+            const float fx0 = floorf(sx), fy0 = floorf(sy);
+            const float wx = sx - fx0, wy = sy - fy0;
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            float d = 0.f;
+            if (tap) {
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const int yy = y0 + cy, xx = x0 + cx;
+                        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                            const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
+                            d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
+                        }
+                    }
+            }
+            d = quad_sum(d);
+            logit[r] = tap ? d * scale : -3.0e38f;
+            mx = fmaxf(mx, logit[r]);
+        }
+    }
+    mx = slot_max(mx);
+    float sp = 0.f, sc = 0.f;
+    float best = -3.0e38f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
+        if (r < rounds) {
+            const int t = r * 16 + slot;
+            const float e = t < nd ? __expf(logit[r] - mx) : 0.f;
+            sp += e;
+            sc += e * cv[r];
+            if (t < nd && logit[r] > best) { best = logit[r]; besti = t; }
+        }
+    }
+    sp = slot_sum(sp);
+    sc = slot_sum(sc);
+    float res = sc / sp;
+    if (from_argmax) {   // first index attaining the maximum
+        const int cand_i = (best == mx) ? besti : 0x7fffffff;
+        int mi = cand_i;
+        mi = min(mi, __shfl_xor(mi, 4));
+        mi = min(mi, __shfl_xor(mi, 8));
+        mi = min(mi, __shfl_xor(mi, 16));
+        mi = min(mi, __shfl_xor(mi, 32));
+        res = cand[mi];
+    }
+    return res;
+}
+
 __global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __restrict__ f0,
                                                                  const float* __restrict__ f1,
                                                                  const float* __restrict__ cam,
@@ -396,11 +476,8 @@ __global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __
                                                                  float* __restrict__ out, int batch, int h, int w,
                                                                  int nd, int from_argmax) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = lane >> 2, quarter = lane & 3;
     const int L = h * w;
     const long total = (long)batch * L;
-    const int rounds = (nd + 15) >> 4;
-    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
     for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
         const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
         const int y = p / w, x = p - y * w;
@@ -413,72 +490,130 @@ __global__ __launch_bounds__(256) void depth_corr_softmax_kernel(const float* __
         const float q0 = cm[9] * r0 + cm[10] * r1 + cm[11] * r2;
         const float q1 = cm[12] * r0 + cm[13] * r1 + cm[14] * r2;
         const float q2 = cm[15] * r0 + cm[16] * r1 + cm[17] * r2;
-        f32x4 a[8];
-        load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
-        float logit[LOCAL_MAX_ROUNDS], cv[LOCAL_MAX_ROUNDS];
-        float mx = -3.0e38f;
+        const float res = depth_pixel_gather(f0, f1, cm, cand, pid, b, h, w, nd, from_argmax, q0, q1, q2, lane);
+        if (lane == 0) out[pid] = res;
+    }
+}
+
+// Round 4: the plane sweep by its integer neighbourhood (as the cost volume, matching.py:86-123, has been since round 1).  The
+// candidates of one pixel walk along its epipolar line in sub-pixel steps (config 5: 64 inverse depths over ~16 feature cells), so
+// their 4 x 64 bilinear corners are a few dozen DISTINCT f1 rows -- the gather kernel fetched every corner of every candidate: 128 KB
+// per pixel from L2, 9.8 GB per launch at config 5 (17 TB/s: the kernel sat on the L2 -> CU bandwidth; 314 MB of it missed to HBM,
+// profiles/r04_gather_rooflines.txt).  Here: lane = candidate (<= 64); the wave takes the bounding box of the corners that can
+// touch the image, dots f0(p) with every f1 row of the box ONCE (16 rows per round, 4 lanes per row as before), keeps the dots in a
+// wave-private LDS table, and every candidate blends its four corners from the table (a dot product is linear in f1, so the blend of
+// the dots is the dot with the blended row; summation order differs from the gather form by fp32 rounding only).  A box of more
+// than DEPTH_BOX rows (a camera move with a long diagonal epipolar segment) takes the gather path for that pixel.
+#define DEPTH_BOX 160
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
-            logit[r] = -3.0e38f;
-            cv[r] = 0.f;
-            if (r < rounds) {
-                const int t = r * 16 + slot;
-                const bool tap = t < nd;
-                const float ci = cand[tap ? t : 0];
-                cv[r] = ci;
-                const float depth = 1.0f / ci;
-                const float X = q0 * depth + cm[18], Y = q1 * depth + cm[19], Z = q2 * depth + cm[20];
-                const float u = cm[21] * X + cm[22] * Y + cm[23] * Z;
-                const float v = cm[24] * X + cm[25] * Y + cm[26] * Z;
-                const float zz = fmaxf(cm[27] * X + cm[28] * Y + cm[29] * Z, 1e-3f);
-                const float sx = fminf(fmaxf(u / zz, -1.0e6f), 1.0e6f);
-                const float sy = fminf(fmaxf(v / zz, -1.0e6f), 1.0e6f);
-                const float fx0 = floorf(sx), fy0 = floorf(sy);
-                const float wx = sx - fx0, wy = sy - fy0;
-                const int x0 = (int)fx0, y0 = (int)fy0;
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void depth_corr_softmax_box_kernel(const float* __restrict__ f0,
+                                                                     const float* __restrict__ f1,
+                                                                     const float* __restrict__ cam,
+                                                                     const float* __restrict__ cand,
+                                                                     float* __restrict__ out, int batch, int h, int w,
+                                                                     int nd, int from_argmax) {
+    __shared__ float tab_all[4][DEPTH_BOX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 2, quarter = lane & 3;
+    float* tab = tab_all[wave];
+    const int L = h * w;
+    const long total = (long)batch * L;
+    const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
+    for (long pid = (long)blockIdx.x * 4 + wave; pid < total; pid += (long)gridDim.x * 4) {
+        const int b = (int)(pid / L), p = (int)(pid - (long)b * L);
+        const int y = p / w, x = p - y * w;
+        const float* cm = cam + (long)b * 30;
+        const float gx = (float)x, gy = (float)y;
+        const float r0 = cm[0] * gx + cm[1] * gy + cm[2];
+        const float r1 = cm[3] * gx + cm[4] * gy + cm[5];
+        const float r2 = cm[6] * gx + cm[7] * gy + cm[8];
+        const float q0 = cm[9] * r0 + cm[10] * r1 + cm[11] * r2;
+        const float q1 = cm[12] * r0 + cm[13] * r1 + cm[14] * r2;
+        const float q2 = cm[15] * r0 + cm[16] * r1 + cm[17] * r2;
+        // this lane's candidate: the same projection arithmetic, in the same order, as the gather form
+        const bool tap = lane < nd;
+        const float ci = cand[tap ? lane : 0];
+        const float depth = 1.0f / ci;
+        const float X = q0 * depth + cm[18], Y = q1 * depth + cm[19], Z = q2 * depth + cm[20];
+        const float u = cm[21] * X + cm[22] * Y + cm[23] * Z;
+        const float v = cm[24] * X + cm[25] * Y + cm[26] * Z;
+        const float zz = fmaxf(cm[27] * X + cm[28] * Y + cm[29] * Z, 1e-3f);
+        const float sx = fminf(fmaxf(u / zz, -1.0e6f), 1.0e6f);
+        const float sy = fminf(fmaxf(v / zz, -1.0e6f), 1.0e6f);
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const float wx = sx - fx0, wy = sy - fy0;
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        // bounding box of the corners that can lie inside the image: a candidate whose x0 is outside [-1, w-1] has no corner in it
+        const int cx0 = min(max(x0, -1), w - 1), cy0 = min(max(y0, -1), h - 1);
+        const int bx0 = wave_min_i(tap ? cx0 : 0x7fffffff), bx1 = wave_max_i(tap ? cx0 + 1 : -0x7fffffff);
+        const int by0 = wave_min_i(tap ? cy0 : 0x7fffffff), by1 = wave_max_i(tap ? cy0 + 1 : -0x7fffffff);
+        const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+        const int npos = bw * bh;
+        float res;
+        if (npos > DEPTH_BOX) {                              // wave-uniform
+            res = depth_pixel_gather(f0, f1, cm, cand, pid, b, h, w, nd, from_argmax, q0, q1, q2, lane);
+        } else {
+            f32x4 a[8];
+            load32(a, f0 + pid * UM_CHANNELS + 4 * quarter);
+            const float rbw = 1.0f / (float)bw;
+            for (int i0 = 0; i0 < npos; i0 += 16) {
+                const int i = i0 + slot;
+                int ry = (int)((float)i * rbw);               // i / bw for 0 <= i < 160, corrected below
+                ry += ((ry + 1) * bw <= i) ? 1 : 0;
+                ry -= (ry * bw > i) ? 1 : 0;
+                const int py = by0 + ry, px = bx0 + (i - ry * bw);
                 float d = 0.f;
-                if (tap) {
-#pragma unroll
-                    for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                        for (int cx = 0; cx < 2; ++cx) {
-                            const int yy = y0 + cy, xx = x0 + cx;
-                            if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-                                const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
-                                d += wt * dot32(a, f1 + ((long)b * L + yy * w + xx) * UM_CHANNELS + 4 * quarter);
-                            }
-                        }
-                }
+                if (i < npos && py >= 0 && py < h && px >= 0 && px < w)
+                    d = dot32(a, f1 + ((long)b * L + py * w + px) * UM_CHANNELS + 4 * quarter);
                 d = quad_sum(d);
-                logit[r] = tap ? d * scale : -3.0e38f;
-                mx = fmaxf(mx, logit[r]);
+                if (quarter == 0 && i < npos) tab[i] = d;
             }
-        }
-        mx = slot_max(mx);
-        float sp = 0.f, sc = 0.f;
-        float best = -3.0e38f;
-        int besti = 0x7fffffff;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is complete (same wave: LDS executes in order)
+            __builtin_amdgcn_wave_barrier();
+            float d = 0.f;
+            if (tap) {
 #pragma unroll
-        for (int r = 0; r < LOCAL_MAX_ROUNDS; ++r) {
-            if (r < rounds) {
-                const int t = r * 16 + slot;
-                const float e = t < nd ? __expf(logit[r] - mx) : 0.f;
-                sp += e;
-                sc += e * cv[r];
-                if (t < nd && logit[r] > best) { best = logit[r]; besti = t; }
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const int yy = y0 + cy, xx = x0 + cx;
+                        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                            const float wt = (cx ? wx : 1.f - wx) * (cy ? wy : 1.f - wy);
+                            d += wt * tab[(yy - by0) * bw + (xx - bx0)];
+                        }
+                    }
             }
-        }
-        sp = slot_sum(sp);
-        sc = slot_sum(sc);
-        float res = sc / sp;
-        if (from_argmax) {   // first index attaining the maximum
-            const int cand_i = (best == mx) ? besti : 0x7fffffff;
-            int mi = cand_i;
-            mi = min(mi, __shfl_xor(mi, 4));
-            mi = min(mi, __shfl_xor(mi, 8));
-            mi = min(mi, __shfl_xor(mi, 16));
-            mi = min(mi, __shfl_xor(mi, 32));
-            res = cand[mi];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane has read before the next pixel overwrites the table
+            __builtin_amdgcn_wave_barrier();
+            const float logit = tap ? d * scale : -3.0e38f;
+            const float mx = wave_max_f(logit);
+            const float e = tap ? __expf(logit - mx) : 0.f;
+            const float sp = wave_sum_f(e), sc = wave_sum_f(e * ci);
+            res = sc / sp;
+            if (from_argmax) {                                   // first index attaining the maximum
+                const int mi = wave_min_i((tap && logit == mx) ? lane : 0x7fffffff);
+                res = cand[mi];
+            }
         }
         if (lane == 0) out[pid] = res;
     }
@@ -648,7 +783,12 @@ extern "C" int um_depth_corr_softmax(const float* f0, const float* f1, const flo
         return -4;
     }
     ScopedKernelTimer timer(UM_K_DEPTH_CORR, (hipStream_t)stream);
-    hipLaunchKernelGGL(depth_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
-                       (hipStream_t)stream, f0, f1, cam, candidates, out, batch, h, w, num_candidates, from_argmax);
+    static const bool no_box = um_debug_env("UM_DEPTH_NO_BOX") != nullptr;     // A/B switch (diagnostic builds)
+    if (num_candidates <= 64 && !no_box)                       // lane = candidate: the integer-neighbourhood form
+        hipLaunchKernelGGL(depth_corr_softmax_box_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
+                           (hipStream_t)stream, f0, f1, cam, candidates, out, batch, h, w, num_candidates, from_argmax);
+    else
+        hipLaunchKernelGGL(depth_corr_softmax_kernel, dim3(pixel_grid_blocks((long)batch * h * w)), dim3(256), 0,
+                           (hipStream_t)stream, f0, f1, cam, candidates, out, batch, h, w, num_candidates, from_argmax);
     return (int)hipGetLastError();
 }
