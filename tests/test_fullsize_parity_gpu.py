@@ -30,7 +30,7 @@ def legs():
     # CPU legs computed elsewhere (tools/parity_fullsize.py --stage cpu --cache gpurun_cache/parity, e.g. in the build container)
     # are picked up when the directory travelled with the tree; otherwise everything is computed here
     cache = os.path.join(ROOT, 'gpurun_cache', 'parity')
-    pool = pf.CpuLegs(cache=cache if os.path.isdir(cache) else None)
+    pool = pf.CpuLegs(workers=12, threads=8, cache=cache if os.path.isdir(cache) else None)
     # queue every sample of every case up front: the pool works through them while the GPU tests run
     pool.submit([(cfg, which, KIND, SEED, i) for cfg, which in CASES for i in range(pf.RUNS[cfg][3])])
     yield pool

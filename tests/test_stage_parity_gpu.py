@@ -26,7 +26,9 @@ CASES = [(cfg, kind) for cfg in (3, 4) for kind in ('shift', 'noise')]
 @pytest.fixture(scope='module')
 def legs():
     cache = os.path.join(ROOT, 'gpurun_cache', 'stage')         # CPU legs computed elsewhere, when the directory travelled
-    pool = sp.StageLegs(cache=cache if os.path.isdir(cache) else None)
+    # 8 workers x 8 threads: the full-size parity suite's pool (tests/test_fullsize_parity_gpu.py) runs at the same time, and
+    # fp64 GEMM threads beyond the physical cores only slow both down
+    pool = sp.StageLegs(workers=8, threads=8, cache=cache if os.path.isdir(cache) else None)
     pool.submit([(cfg, 'ctor326', kind, SEED, i) for cfg, kind in CASES for i in range(sp.pf.RUNS[cfg][3])])
     yield pool
     pool.close()
