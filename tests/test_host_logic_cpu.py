@@ -281,3 +281,20 @@ def test_hot_path_fails_loudly_without_gpu():
     model, sd, i0, i1, kw, ck = build('gmflow_s1')
     with pytest.raises(_abi.HipExtensionError):
         model(i0, i1, **kw)
+
+
+def test_kv4_weight_packing_matches_the_header():
+    """include/unimatch_hip.h (um_kv4_fwd): Wc[32 c + r][0:128] = W4[32 c + r], Wc[32 c + r][128:256] = W4[256 + 32 c + (r ^ 16)]."""
+    from unimatch_amd.ops import pack_kv4_weights
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(128, 128, generator=g) for _ in range(4)]
+    wc = pack_kv4_weights(ws)
+    w4 = torch.cat(ws, 0)
+    assert wc.shape == (256, 256) and wc.is_contiguous()
+    for c in range(8):
+        for r in range(32):
+            assert torch.equal(wc[32 * c + r, :128], w4[32 * c + r])
+            assert torch.equal(wc[32 * c + r, 128:], w4[256 + 32 * c + (r ^ 16)])
+    # every output row of the four projections appears exactly once
+    rows = torch.cat([wc[:, :128], wc[:, 128:]], 0)
+    assert torch.equal(rows.sort(0).values, w4.sort(0).values)

@@ -54,6 +54,17 @@ def _check_map(name, t, n, h, w):
                          f'{tuple(t.shape)} {t.dtype}')
 
 
+def pack_kv4_weights(weights):
+    """The four ``[128, 128]`` projection weights (k_self, v_self, k_cross, v_cross) packed as the ``[256, 256]`` matrix
+    ``um_kv4_fwd`` / ``um_ffn_kv_fwd`` stream like a W1 slice of the FFN: row ``32 c + r`` (chunk c = 0..7, r = 0..31) carries
+    ``W4[32 c + r]`` in columns 0..127 (the rows role 0 of a wave pair multiplies: k_self | v_self) and ``W4[256 + 32 c + (r ^ 16)]``
+    in columns 128..255 (role 1 reads ring rows permuted by ^16: k_cross | v_cross), ``W4`` = the four weights stacked."""
+    w4 = torch.cat([w.detach().float() for w in weights], 0)                         # [512, 128]
+    perm = torch.arange(32, device=w4.device) ^ 16
+    cross = w4[256:].view(8, 32, 128)[:, perm].reshape(256, 128)
+    return torch.cat([w4[:256], cross], 1).contiguous()
+
+
 class HipOps:
     """The hot path on MI355X.  ``precision``: 'exact' (fp16 hi+lo split MFMA operands) or 'fast' (bf16)."""
 
@@ -365,10 +376,7 @@ class HipOps:
             return hit
         if len(weights) != 4 or any(tuple(w.shape) != (128, 128) for w in weights):
             raise ValueError('kv4_weight_planes: expected four [128, 128] weights (k_self, v_self, k_cross, v_cross)')
-        w4 = torch.cat([w.detach().float() for w in weights], 0)                     # [512, 128]
-        perm = torch.arange(32, device=w4.device) ^ 16
-        cross = w4[256:].view(8, 32, 128)[:, perm].reshape(256, 128)
-        wc = torch.cat([w4[:256], cross], 1).contiguous()                            # [256, 256]
+        wc = pack_kv4_weights(weights)                                               # [256, 256]
         self._check_weight_range(wc, self.WSHIFT if self.mode == 0 else 0, 'Linear weight')
         planes = torch.empty(self.lib.um_planes_bytes(256, 256, self.mode), dtype=torch.uint8, device=wc.device)
         _abi.check(self.lib.um_weight_planes(_ptr(wc), _ptr(planes), 256, 256, self.WSHIFT, self.mode, _stream()), 'um_weight_planes')
