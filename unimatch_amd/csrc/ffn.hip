@@ -101,6 +101,14 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 #ifndef UM_FFN_PRIO
 #define UM_FFN_PRIO 0
 #endif
+// Who requests the weight slices (UM_FFN_ORDER 1).  0: every wave its sixth of the slice (6 LDS-DMA statements per wave and slice).
+// 1: the ROLE-0 waves request everything (12 statements each), the role-1 waves none: role 0 is the older wave of its SIMD, the
+// arbiter serves it first and it finishes its stream ~750 cycles before its partner (section stamps) -- the requests cost issue
+// slots, not matrix-pipe time, so moving them to the wave that has the slack shortens the partner's stream, which is the one the
+// slice waits for.
+#ifndef UM_FFN_DMA_ASYM
+#define UM_FFN_DMA_ASYM 0
+#endif
 #ifndef UM_FFN_ABL
 #define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
 #endif
@@ -387,6 +395,24 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
             const unsigned off = (unsigned)((((long)r) * a.hid + 32 * (sbase + jw2) + 8 * c) * 2);
             ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
+        }
+    };
+
+    // UM_FFN_DMA_ASYM: the role-0 wave of pair p requests a quarter of the slice: k = 0..7: W1 rows 2 (4 (k >> 1) + p) + half, plane
+    // k & 1;  k = 8..11: W2 rows 16 (2 p + ((k - 8) >> 1)) + lane / 4, plane k & 1
+    auto dma_piece_asym = [&](int k, int jw1, int jw2, int slot) {
+        const int pl = k & 1;
+        if (pl >= NS) return;
+        if (k < 8) {
+            const int blk = 4 * (k >> 1) + pair;
+            const int r = 2 * blk + half, c = tl ^ r;
+            const unsigned off = (unsigned)((((long)(32 * (sbase + jw1) + r)) * 256 + 8 * c) * 2);
+            ffn_dma16(a.w1 + pl * a.w1_plane_stride, off, lds + L::W1_OFF + slot * L::W1S + pl * L::W1P + blk * 1024);
+        } else {
+            const int blk = 2 * pair + ((k - 8) >> 1);
+            const int r = 16 * blk + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+            const unsigned off = (unsigned)((((long)r) * a.hid + 32 * (sbase + jw2) + 8 * c) * 2);
+            ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + blk * 1024);
         }
     };
 
@@ -703,13 +729,19 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         };
         // LDS-DMA pieces still to issue: W1(i+2) (4 statements at NS = 2) when it exists, W2(i) (2 statements); one per MFMA gap
         // from gap 1 on (gap 0 carries the exchange arithmetic)
-        int piece = DMA1 ? 0 : 4;
+        int piece = UM_FFN_DMA_ASYM ? (DMA1 ? 0 : 8) : (DMA1 ? 0 : 4);
+        constexpr int NPIECE = UM_FFN_DMA_ASYM ? 12 : 6;
         auto dma_share = [&](int slot_idx) {
             if (UM_FFN_ABL & 2) return;
-            if (slot_idx >= 1 && piece < 6) {
-                dma_piece(piece, i + 2, i, slot);
-                ++piece;
-                if (NS == 1 && (piece == 1 || piece == 3)) ++piece;        // (one plane: pieces 1, 3, 5 do not exist)
+            if (slot_idx >= 1 && piece < NPIECE) {
+                if (UM_FFN_DMA_ASYM) {
+                    if (role == 0) dma_piece_asym(piece, i + 2, i, slot);
+                    piece += (NS == 1) ? 2 : 1;                            // (one plane: the odd pieces do not exist)
+                } else {
+                    dma_piece(piece, i + 2, i, slot);
+                    ++piece;
+                    if (NS == 1 && (piece == 1 || piece == 3)) ++piece;    // (one plane: pieces 1, 3, 5 do not exist)
+                }
             }
         };
         f32x16 scn, scm;
@@ -805,10 +837,15 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             else frag_stage(fr, g, pfn, done - NGELU);
         }
         if (!(UM_FFN_ABL & 2)) {
-            while (piece < 6) {                                    // pieces no gap took (ablation builds without MFMAs)
-                dma_piece(piece, i + 2, i, slot);
-                ++piece;
-                if (NS == 1 && (piece == 1 || piece == 3)) ++piece;
+            while (piece < NPIECE) {                               // pieces no gap took (short streams: one plane, ablation builds)
+                if (UM_FFN_DMA_ASYM) {
+                    if (role == 0) dma_piece_asym(piece, i + 2, i, slot);
+                    piece += (NS == 1) ? 2 : 1;
+                } else {
+                    dma_piece(piece, i + 2, i, slot);
+                    ++piece;
+                    if (NS == 1 && (piece == 1 || piece == 3)) ++piece;
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
