@@ -266,6 +266,15 @@ int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long
                       float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld, void* out_planes, int outp_ld,
                       int outp_coff, long outp_rows, int batch, int hi, int wi, int cin, int channels, int kh, int kw, int pad_h,
                       int pad_w, int wshift, int mode, void* stream);
+/* The same with a per-pixel addend (fp32 [rows][addend_ld]; column = output channel of the convolution: 2 * channels for gate 1,
+ * channels for gate 2), added to the scaled accumulator (+ bias) BEFORE the gate's activation.  A convolution is linear in its input
+ * channels: the refinement loop (unimatch/unimatch.py:315-331) restarts its hidden state from the same net0 and feeds the same
+ * context features `inp` in every iteration, so their share of every gate convolution is computed ONCE per scale (um_conv2d_ex,
+ * no activation) and the per-iteration convolutions only read the channels that change (round 4; unimatch_amd/refine_nhwc.py). */
+int um_conv2d_gru_add_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
+                          const float* addend, int addend_ld, float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld,
+                          void* out_planes, int outp_ld, int outp_coff, long outp_rows, int batch, int hi, int wi, int cin,
+                          int channels, int kh, int kw, int pad_h, int pad_w, int wshift, int mode, void* stream);
 /* stats_out (optional): per output tile part (<= 128 pixels, in the order of the serving kernel's tiles) the (mean, pixel
  * count, sum of squared deviations) of every output channel, computed in the epilogue from the tile that is in LDS anyway.
  * um_conv_stats_parts() = parts per image for that geometry (the stem, um_conv7_fwd / um_stem_conv_fwd: kh = kw = 7,

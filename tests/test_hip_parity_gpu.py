@@ -828,6 +828,22 @@ def test_nhwc_update_block_matches_module(ops, fd, hw):
     # a second iteration must not depend on state left by the first (the hidden state restarts from net0)
     mask2, delta2 = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
     assert torch.equal(delta2, delta) and torch.equal(mask2, mask)
+    # round 4: with more than one iteration announced, the iteration-invariant share of the four gate convolutions (context
+    # features, initial hidden state: unimatch.py:315-331) is computed once in begin() and enters the per-iteration convolutions as
+    # their epilogue's addend (um_conv2d_gru_add_fwd): same result up to fp32 summation order, again independent of earlier iterations
+    assert not upd.hoist
+    hst = NhwcUpdateBlock(ops, block, proj)
+    hst.begin(f0.to(DEV), b, h, w, iterations=3)
+    assert hst.hoist
+    mask_h, delta_h = hst.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert err(delta_h, delta64)[0] < 2e-5 * max(1.0, delta64.abs().max().item())
+    assert err(mask_h.view(b, h, w, -1).permute(0, 3, 1, 2), mask64)[0] < 2e-5 * max(1.0, mask64.abs().max().item())
+    assert err(delta_h, delta)[0] < 1e-5 * max(1.0, delta64.abs().max().item())
+    flow2 = flow + 0.25
+    disp2 = torch.cat([-flow2, torch.zeros_like(flow2)], 1) if fd == 1 else flow2
+    hst.iterate(ori0.to(DEV), ori1.to(DEV), disp2.to(DEV).contiguous(), flow2.to(DEV), False)      # another input in between
+    mask_h2, delta_h2 = hst.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert torch.equal(delta_h2, delta_h) and torch.equal(mask_h2, mask_h)
 
 
 @pytest.mark.parametrize('bhw,normalize', [((2, 64, 96), True), ((1, 37, 51), False), ((3, 16, 32), True)])

@@ -259,7 +259,7 @@ def gpu_stage(name, G, model, ck, kw, img0, img1):
         last = t == kw.get('num_reg_refine', 1) - 1
         if getattr(ops, 'fused_conv', False):    # the product's path: channels-last block, K4 writes convc1's operand planes
             nhwc = NhwcUpdateBlock(ops, model.refine, model.refine_proj)
-            nhwc.begin(_tok(G[f'f0_s{ls}']), nb, h, w)
+            nhwc.begin(_tok(G[f'f0_s{ls}']), nb, h, w, iterations=kw.get('num_reg_refine', 1))    # the product's (hoisted) form
             mask, delta = nhwc.iterate(ori0, ori1, disp, flow, last)
             mask = mask.reshape(nb, h, w, -1).permute(0, 3, 1, 2) if mask is not None else None
         else:                                    # injected CPU backend (harness dry run)

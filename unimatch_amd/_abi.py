@@ -52,6 +52,8 @@ SIGNATURES = {
     'um_local_corr_with_flow_planes': (_c_int, [_c_void_p] * 4 + [_c_int, ctypes.c_long] + [_c_int] * 5 + [_c_void_p]),
     'um_conv2d_gru_fwd': (_c_int, [_c_int, _c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                    _c_void_p, _c_int, _c_void_p, _c_int, _c_int, ctypes.c_long] + [_c_int] * 11 + [_c_void_p]),
+    'um_conv2d_gru_add_fwd': (_c_int, [_c_int, _c_void_p, _c_int, _c_int, ctypes.c_long, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                        _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, ctypes.c_long] + [_c_int] * 11 + [_c_void_p]),
     'um_conv_stats_bytes': (_c_size_t, [_c_int] * 3),
     'um_conv_stats_parts': (_c_int, [_c_int] * 8),
     'um_stem_planes_bytes': (_c_size_t, [_c_int] * 3),

@@ -56,6 +56,11 @@ struct ConvArgs {
     float* gate_h;
     const float* gate_z;
     float* stats;                 // optional [M / 128][3][Cout]: per 128-pixel tile (mean, 0, sum of squared deviations)
+    // optional per-pixel addend, fp32 [M][addend_ld]: added to the scaled accumulator (+ bias) BEFORE the activation.  A convolution is
+    // linear in its input channels, so the contribution of input channels that do not change between calls (the refinement loop's
+    // context features and initial hidden state, unimatch.py:315-331) is computed once and comes in here (round 4).
+    const float* addend;
+    int addend_ld;
     int B, Hi, Wi, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad_h, pad_w;
     int M;                        // B * Ho * Wo
@@ -122,7 +127,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         if (a.bias) to_lds(act_tag, IntC<1>{});
         else to_lds(act_tag, IntC<0>{});
     };
-    switch (a.act) {
+    switch (a.addend ? 0 : a.act) {                               // with an addend the activation waits for it (store_rows)
         case 0: to_lds_b(IntC<0>{}); break;
         case 1: to_lds_b(IntC<1>{}); break;
         case 2: to_lds_b(IntC<2>{}); break;
@@ -211,6 +216,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         unsigned short* pbase = a.outp ? a.outp + rowbase * a.outp_ld + a.outp_coff : nullptr;
         float* hbase = GATE ? a.gate_h + rowbase * a.gate_c : nullptr;
         const float* zbase = GATE == 2 ? a.gate_z + rowbase * a.gate_zld : nullptr;
+        const float* abase = a.addend ? a.addend + rowbase * a.addend_ld : nullptr;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = it * 64 + lane;
@@ -218,6 +224,15 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
             f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
             int col = nb + 4 * c;
             if (r < nrows && col < a.Cout) {
+                if (abase) {                                      // full-row reads, then the activation that waited for them
+                    d = d + *reinterpret_cast<const f32x4*>(abase + (unsigned)(r * a.addend_ld + col));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (a.act == 1) d[i] = fmaxf(d[i], 0.f);
+                        else if (a.act == 2) d[i] = 1.0f / (1.0f + __expf(-d[i]));
+                        else if (a.act == 3) d[i] = tanhf(d[i]);
+                    }
+                }
                 bool to_out = obase != nullptr, to_planes = pbase != nullptr;
                 if (GATE == 1) {
                     if (col >= a.gate_c) {
@@ -895,7 +910,11 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
                        float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
                        float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
                        int pad_h, int pad_w, int act, int wshift, int mode, void* stream_, int gate, float* gate_h,
-                       const float* gate_z, int gate_zld) {
+                       const float* gate_z, int gate_zld, const float* addend = nullptr, int addend_ld = 0) {
+    if (addend && (addend_ld < cout || addend_ld % 4 != 0 || ((unsigned long)addend & 15) != 0 || stats_out)) {
+        um_set_error("um_conv2d: the addend must be 16-byte aligned fp32 [M][ld >= cout, ld %% 4 == 0] (and excludes fused statistics)");
+        return -1;
+    }
     if (!a_planes || !w_planes || (!out && !out_planes) || batch <= 0 || hi <= 0 || wi <= 0 || cin <= 0 || cin % 32 != 0 ||
         cout <= 0 || cout % 4 != 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1) ||
         wshift < 0 || wshift > 14 || act < 0 || act > 3) {
@@ -944,6 +963,8 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     a.outp_coff = outp_coff;
     a.outp_plane_stride = outp_rows * outp_ld;
     a.stats = stats_out;
+    a.addend = addend;
+    a.addend_ld = addend_ld;
     a.B = batch;
     a.Hi = hi;
     a.Wi = wi;
@@ -1005,6 +1026,28 @@ extern "C" int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a
     // q: tanh; hidden <- (1 - z) hidden + z q, also written as planes
     return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, nullptr, 0, 0, out_planes, outp_ld, outp_coff, outp_rows,
                        nullptr, batch, hi, wi, cin, channels, kh, kw, 1, pad_h, pad_w, 3, wshift, mode, stream_, 2, hidden, z, z_ld);
+}
+
+// um_conv2d_gru_fwd with a per-pixel addend (fp32 [rows][addend_ld], column = output channel of the convolution: 2 * channels for
+// gate 1, channels for gate 2) added before the gate's activation: the contribution of the input channels that are the same in every
+// refinement iteration, computed once per scale with um_conv2d_ex (unimatch_amd/refine_nhwc.py).
+extern "C" int um_conv2d_gru_add_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes,
+                                     const float* bias, const float* addend, int addend_ld, float* hidden, const float* z, int z_ld,
+                                     float* z_out, int z_out_ld, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
+                                     int batch, int hi, int wi, int cin, int channels, int kh, int kw, int pad_h, int pad_w,
+                                     int wshift, int mode, void* stream_) {
+    if ((gate != 1 && gate != 2) || !hidden || !out_planes || !addend || channels <= 0 || channels % 4 != 0 || (gate == 1 && !z_out) ||
+        (gate == 2 && !z)) {
+        um_set_error("um_conv2d_gru_add_fwd: bad argument (gate=%d channels=%d)", gate, channels);
+        return -1;
+    }
+    if (gate == 1)
+        return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, z_out, z_out_ld, 0, out_planes, outp_ld, outp_coff,
+                           outp_rows, nullptr, batch, hi, wi, cin, 2 * channels, kh, kw, 1, pad_h, pad_w, 2, wshift, mode, stream_,
+                           1, hidden, nullptr, 0, addend, addend_ld);
+    return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, nullptr, 0, 0, out_planes, outp_ld, outp_coff, outp_rows,
+                       nullptr, batch, hi, wi, cin, channels, kh, kw, 1, pad_h, pad_w, 3, wshift, mode, stream_, 2, hidden, z, z_ld,
+                       addend, addend_ld);
 }
 
 extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,
@@ -1126,6 +1169,8 @@ extern "C" int um_conv7_fwd(const float* image, int channels, int normalize, con
     a.outp_coff = outp_coff;
     a.outp_plane_stride = outp_rows * outp_ld;
     a.stats = stats_out;
+    a.addend = nullptr;
+    a.addend_ld = 0;
     a.B = batch;
     a.Hi = hp;
     a.Wi = wp;

@@ -573,7 +573,7 @@ class UniMatch(nn.Module):
                 nhwc = None                                     # channels-last refinement block on the library's convolutions
                 if getattr(ops, 'fused_conv', False) and tok0.is_cuda:      # every task: flow_dim 2 (flow) / 1 (disparity, inverse depth)
                     nhwc = NhwcUpdateBlock(ops, self.refine, self.refine_proj)
-                    nhwc.begin(tok0, tok0.shape[0], h, w)
+                    nhwc.begin(tok0, tok0.shape[0], h, w, iterations=num_reg_refine)
                 else:
                     proj = self.refine_proj(f0_map)             # same every iteration (unimatch.py:315-320)
                     net0, inp = torch.tanh(proj[:, :128]), torch.relu(proj[:, 128:])

@@ -73,6 +73,7 @@ class HipOps:
     fused_merge = True         # merge + LayerNorm (+ residual) in the attention kernel's epilogue
     fused_qproj = True         # ... and the query projection in its prologue (um_window_attn_qproj_merge_fwd)
     block_kv = True            # one k | v projection launch per Transformer block (both layers' keys / values: um_kv4_fwd)
+    refine_hoist = True        # refinement loop: the iteration-invariant share of the GRU gate convolutions computed once per scale
     fused_kv = True            # ... which, from block 1 on, is the previous block's FFN epilogue (um_ffn_kv_fwd): no launch at all
     # (class attributes: tests and tools/ab_bench.py flip them programmatically; the product reads no environment variable)
     fused_conv = True          # encoder convolutions + InstanceNorm in NHWC on um_conv2d_fwd / um_nhwc_instance_norm
@@ -574,9 +575,11 @@ class HipOps:
             {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin})
         _abi.check(code, 'um_conv2d_ex')
 
-    def conv_gru(self, gate, src, geom, wb, ksize, pad, hidden, outp, z=None, z_out=None):
+    def conv_gru(self, gate, src, geom, wb, ksize, pad, hidden, outp, z=None, z_out=None, addend=None):
         """``um_conv2d_gru_fwd``: gate 1 = (z | r) convolution -> ``z_out`` fp32 and ``r * hidden`` planes; gate 2 = q
-        convolution -> ``hidden`` updated in place and written as planes.  ``src`` / ``wb`` / ``outp`` as :meth:`conv_ex`."""
+        convolution -> ``hidden`` updated in place and written as planes.  ``src`` / ``wb`` / ``outp`` as :meth:`conv_ex`.
+        ``addend``: fp32 ``[rows, cout]`` added before the gate's activation (``um_conv2d_gru_add_fwd``: the iteration-invariant
+        input channels' share of the convolution, computed once per scale)."""
         buf, a_ld, a_coff, cin = src
         b, h, w = geom
         (wp, cout, wcin, kh, kw), bias = wb
@@ -585,6 +588,17 @@ class HipOps:
             raise ValueError('conv_gru: weight / hidden shapes do not match')
         p_t, p_ld, p_coff = outp
         zt = z if gate == 2 else None
+        if addend is not None:
+            if not (addend.dtype == torch.float32 and addend.is_contiguous() and addend.shape[1] == cout):
+                raise ValueError('conv_gru: addend must be contiguous fp32 [rows, cout]')
+            code = self._launch('conv', lambda: self.lib.um_conv2d_gru_add_fwd(
+                gate, _ptr(buf), a_ld, a_coff, buf.numel() // (4 * a_ld), _ptr(wp), _ptr(bias) if bias is not None else None,
+                _ptr(addend), addend.shape[1], _ptr(hidden), _ptr(zt) if zt is not None else None,
+                zt.shape[1] if zt is not None else 0, _ptr(z_out) if z_out is not None else None,
+                z_out.shape[1] if z_out is not None else 0, _ptr(p_t), p_ld, p_coff, p_t.numel() // (4 * p_ld), b, h, w, cin, c,
+                kh, kw, pad[0], pad[1], self.WSHIFT, 0, _stream()), {'flops': 2.0 * b * h * w * cout * kh * kw * cin})
+            _abi.check(code, 'um_conv2d_gru_add_fwd')
+            return
         code = self._launch('conv', lambda: self.lib.um_conv2d_gru_fwd(
             gate, _ptr(buf), a_ld, a_coff, buf.numel() // (4 * a_ld), _ptr(wp), _ptr(bias) if bias is not None else None,
             _ptr(hidden), _ptr(zt) if zt is not None else None, zt.shape[1] if zt is not None else 0,
