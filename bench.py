@@ -78,6 +78,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (cfg2, default 8) / global batch (cfg4, default 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='run the timed steps as eager launches instead of replaying the HIP graph of the forward (unimatch_amd.graph)')
     ap.add_argument('--cpu-iters', type=int, default=8)
     ap.add_argument('--set', action='append', default=[], metavar='Class.attr=value',
                     help='A/B knob for tools/ab_bench.py: set a class attribute of HipOps / CNNEncoder before the run, e.g. '
@@ -250,10 +252,15 @@ def main():
             torch.cuda.current_stream(dev).wait_event(pending['event'])
             pending['event'] = pending['src'] = None
 
+    # The timed steps replay the HIP graph of the forward (one capture per precision, bitwise equal to the eager launches:
+    # tests/test_hip_parity_gpu.py::test_hip_graph_replay_matches_eager); --no-graph and the breakdown pass launch eagerly.
+    launch = {'fwd': model, 'mode': 'eager'}
+
     def step():
         if cfg4:
+            runner.model = launch['fwd']
             return runner(i0, i1, **fk)['flow_preds'][0]          # [global batch, 2, H, W] on every rank
-        pred = model(i0, i1, **fk)['flow_preds'][0]
+        pred = launch['fwd'](i0, i1, **fk)['flow_preds'][0]
         if distributed:
             finish_gather()
             src = pred.contiguous()
@@ -272,8 +279,14 @@ def main():
     def timed(precision, steps, warmup):
         """The headline region: K steps, barrier + synchronize on both sides, no per-kernel event inside."""
         model.set_precision(precision)
-        for _ in range(warmup):
+        launch['fwd'], launch['mode'] = model, 'eager'
+        if not args.no_graph:
+            from unimatch_amd.graph import GraphedUniMatch
+            launch['fwd'], launch['mode'] = GraphedUniMatch(model), 'hip_graph_replay'      # captured by the first warm-up step
+        for _ in range(max(warmup, 1)):
             pred = step()
+        if launch['mode'] != 'eager' and any(v is False for v in launch['fwd']._graphs.values()):
+            launch['fwd'], launch['mode'] = model, 'eager (HIP graph capture failed)'
         finish_gather()
         torch.cuda.synchronize()
         lib.um_timing_enable(0)
@@ -300,7 +313,9 @@ def main():
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
-        return elapsed, pred
+        mode_used = launch['mode']
+        launch['fwd'], launch['mode'] = model, 'eager'             # the breakdown pass needs the library's per-launch events
+        return elapsed, pred, mode_used
 
     def breakdown(steps):
         """After the headline region: the same steps with the library's per-kernel hipEvents -- one pass timing only the launches
@@ -340,14 +355,14 @@ def main():
         enc_wall = sum(a.elapsed_time(b_) for a, b_ in spans) / max(len(spans), 1)
         return out[0], out[1], enc_wall
 
-    elapsed, pred = timed(args.precision, args.steps, args.warmup)
+    elapsed, pred, launch_mode = timed(args.precision, args.steps, args.warmup)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     spread_ms = (step_ms[0], step_ms[-1])
     hot_t, enc_t, enc_wall_ms = breakdown(args.steps)
     other = 'fast' if args.precision == 'exact' else 'exact'
     extra = None
     if not args.no_fast:
-        e_el, e_pred = timed(other, args.steps, max(2, args.warmup // 2))
+        e_el, e_pred, _ = timed(other, args.steps, max(2, args.warmup // 2))
         extra = (e_el, e_pred) + breakdown(args.steps)
         model.set_precision(args.precision)
     rccl_ranks = gather.ranks() if gather is not None else 1
@@ -510,7 +525,7 @@ def main():
         'dtype': 'f16x2' if args.precision == 'exact' else 'bf16',
         'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,
         'config': {'workload': workload,
-                   'per_gpu_batch': b, 'global_batch': gb, 'precision': args.precision,
+                   'per_gpu_batch': b, 'global_batch': gb, 'precision': args.precision, 'launch_mode': launch_mode,
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; every '
                                      'GEMM / convolution of the forward runs on the library\'s own split-fp16 MFMA kernels '
                                      '(no MIOpen, hipBLASLt or rocBLAS kernel in the forward)',
@@ -526,7 +541,8 @@ def main():
         'hot_path_kernels_ms_per_step': hot_per, 'encoder_kernels_ms_per_step': enc_per,
         'untimed_ms_per_step': round(median_ms - hot_ms - enc_ms, 3),
         'hot_path_pairs_per_sec': round((b if not cfg4 else b) / (hot_ms * 1e-3), 1) if hot_ms else None,
-        'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps).  roofline durations, '
+        'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps), the forward replayed as a HIP '
+                       'graph unless --no-graph (config.launch_mode; same kernels, same results, ~1 % less launch overhead).  roofline durations, '
                        'hot_path_ms_per_step (kernel-duration sum of everything outside the CNN encoder = SURVEY 8\'s path) and '
                        'encoder_ms_per_step (the encoder\'s launches, SURVEY 2 #8, out of scope) come from a separate breakdown '
                        'pass of the same K steps with per-kernel hipEvents on the launch stream; hot_path_pairs_per_sec = this '
