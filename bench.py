@@ -78,8 +78,10 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (cfg2, default 8) / global batch (cfg4, default 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
-    ap.add_argument('--no-graph', action='store_true',
-                    help='run the timed steps as eager launches instead of replaying the HIP graph of the forward (unimatch_amd.graph)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the HIP graph of the forward (unimatch_amd.graph) in the timed steps instead of launching eagerly '
+                         '(measured on MI355X at config 2: 817.5 / 817.0 pairs/s against 818.6 / 819.1 eager -- the step is GPU-bound, '
+                         'the default stays eager)')
     ap.add_argument('--cpu-iters', type=int, default=8)
     ap.add_argument('--set', action='append', default=[], metavar='Class.attr=value',
                     help='A/B knob for tools/ab_bench.py: set a class attribute of HipOps / CNNEncoder before the run, e.g. '
@@ -252,8 +254,8 @@ def main():
             torch.cuda.current_stream(dev).wait_event(pending['event'])
             pending['event'] = pending['src'] = None
 
-    # The timed steps replay the HIP graph of the forward (one capture per precision, bitwise equal to the eager launches:
-    # tests/test_hip_parity_gpu.py::test_hip_graph_replay_matches_eager); --no-graph and the breakdown pass launch eagerly.
+    # --graph: the timed steps replay the HIP graph of the forward (one capture per precision, bitwise equal to the eager launches:
+    # tests/test_hip_parity_gpu.py::test_hip_graph_replay_matches_eager); the default and the breakdown pass launch eagerly.
     launch = {'fwd': model, 'mode': 'eager'}
 
     def step():
@@ -280,7 +282,7 @@ def main():
         """The headline region: K steps, barrier + synchronize on both sides, no per-kernel event inside."""
         model.set_precision(precision)
         launch['fwd'], launch['mode'] = model, 'eager'
-        if not args.no_graph:
+        if args.graph:
             from unimatch_amd.graph import GraphedUniMatch
             launch['fwd'], launch['mode'] = GraphedUniMatch(model), 'hip_graph_replay'      # captured by the first warm-up step
         for _ in range(max(warmup, 1)):
@@ -541,8 +543,8 @@ def main():
         'hot_path_kernels_ms_per_step': hot_per, 'encoder_kernels_ms_per_step': enc_per,
         'untimed_ms_per_step': round(median_ms - hot_ms - enc_ms, 3),
         'hot_path_pairs_per_sec': round((b if not cfg4 else b) / (hot_ms * 1e-3), 1) if hot_ms else None,
-        'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps), the forward replayed as a HIP '
-                       'graph unless --no-graph (config.launch_mode; same kernels, same results, ~1 % less launch overhead).  roofline durations, '
+        'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps), eager launches (--graph replays '
+                       'the forward as a HIP graph: no gain, the step is GPU-bound; config.launch_mode).  roofline durations, '
                        'hot_path_ms_per_step (kernel-duration sum of everything outside the CNN encoder = SURVEY 8\'s path) and '
                        'encoder_ms_per_step (the encoder\'s launches, SURVEY 2 #8, out of scope) come from a separate breakdown '
                        'pass of the same K steps with per-kernel hipEvents on the launch stream; hot_path_pairs_per_sec = this '
