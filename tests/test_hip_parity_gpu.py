@@ -844,6 +844,24 @@ def test_nhwc_update_block_matches_module(ops, fd, hw):
     hst.iterate(ori0.to(DEV), ori1.to(DEV), disp2.to(DEV).contiguous(), flow2.to(DEV), False)      # another input in between
     mask_h2, delta_h2 = hst.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
     assert torch.equal(delta_h2, delta_h) and torch.equal(mask_h2, mask_h)
+    # the six activation plane buffers are allocated and zeroed once per geometry and owner (ops.cached_planes_buffer) and handed
+    # out again by every begin(): nothing may be read that this forward has not written -- poison every row but the zero padding
+    # row with fp16 NaNs (0xffff) and run the forward again
+    planes = {k: v for k, v in ops._split_ws.items() if isinstance(k[0], tuple) and k[0][2] == b * h * w}
+    assert {k[0][1] for k in planes} == {'G', 'C1', 'CF', 'FH', 'F1', 'CORR'}
+    def poison():
+        for key, buf in planes.items():
+            _, _, rows, ld = key[0]
+            buf.view(torch.int16).view(2, rows + 1, ld)[:, :rows].fill_(-1)
+
+    poison()
+    hst.begin(f0.to(DEV), b, h, w, iterations=3)
+    mask_h3, delta_h3 = hst.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert torch.equal(delta_h3, delta_h) and torch.equal(mask_h3, mask_h)
+    poison()
+    upd.begin(f0.to(DEV), b, h, w)
+    mask3, delta3 = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert torch.equal(delta3, delta) and torch.equal(mask3, mask)
 
 
 @pytest.mark.parametrize('bhw,normalize', [((2, 64, 96), True), ((1, 37, 51), False), ((3, 16, 32), True)])
@@ -1443,8 +1461,9 @@ def test_graph_capture_owns_its_split_workspaces():
     for g in (g1, g2):
         assert torch.equal(next(iter(g._graphs.values()))['out'], eager)
     for ws in (w1, w2):
-        for buf in ws.values():
-            assert int(buf[:64].count_nonzero()) == 0
+        for key, buf in ws.items():
+            if isinstance(key[0], str):                                      # the counters (not the refinement's plane buffers)
+                assert int(buf[:64].count_nonzero()) == 0
     fresh = HipOps('exact')                                                  # first-time request inside a capture: refused
     graph = torch.cuda.CUDAGraph()
     x = rnd(900, 2240, 128).to(DEV)

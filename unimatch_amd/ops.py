@@ -320,7 +320,7 @@ class HipOps:
         owner = self.workspace_owner if self.workspace_owner is not None else _stream()
         key = (name, device, owner)
         buf = cache.get(key)
-        if buf is None or buf.numel() < nbytes:
+        if buf is None or buf.numel() < nbytes or (isinstance(name, tuple) and buf.numel() != nbytes):
             if torch.cuda.is_current_stream_capturing():
                 # would come from the graph's private pool and only be zeroed by a memset NODE: refuse instead of baking in a
                 # buffer whose counters are garbage if this capture aborts
@@ -544,6 +544,18 @@ class HipOps:
     def planes_buffer(self, rows, ld):
         """Zeroed operand-plane buffer ``[2][rows + 1][ld]`` (fp16 hi | lo); row ``rows`` is the zero padding row."""
         return torch.zeros(2 * (rows + 1) * ld * 2, dtype=torch.uint8, device='cuda')
+
+    def cached_planes_buffer(self, tag, rows, ld, device):
+        """A ``planes_buffer(rows, ld)`` that is allocated and zeroed ONCE per (tag, geometry, device, owner) and handed out again on
+        later forwards (the refinement block's six activation buffers are 590 MB of zero-fill per forward at config 4 otherwise).
+        Only the padding row has to be zero and no kernel ever writes it; every other row is written before it is read.  Ownership
+        as for the split workspaces (:meth:`_split_workspace`): per stream, or per captured graph."""
+        name = ('planes', tag, rows, ld)
+        cache = self.__dict__.setdefault('_split_ws', {})
+        owner = self.workspace_owner if self.workspace_owner is not None else _stream()
+        for k in [k for k in cache if isinstance(k[0], tuple) and k[0][:2] == name[:2] and k[0] != name and k[2] == owner]:
+            del cache[k]                       # one geometry per owner stays resident (a new input size replaces the old set)
+        return self._split_workspace(name, 2 * (rows + 1) * ld * 2, device)
 
     def conv_weight_planes_from(self, weight):
         """Uncached: planes of ``weight [cout, cin, kh, kw]`` permuted to ``[cout, kh*kw*cin]`` -> ``(planes, cout, cin, kh, kw)``."""

@@ -99,10 +99,11 @@ class NhwcUpdateBlock:
         self.b, self.h, self.w = b, h, w
         rows = self.rows = b * h * w
         self.wts = self._weights()
-        self.G = ops.planes_buffer(rows, 512)
-        self.C1, self.CF, self.FH = (ops.planes_buffer(rows, 256) for _ in range(3))
-        self.F1 = ops.planes_buffer(rows, 128)
-        self.CORR = ops.planes_buffer(rows, 96)
+        dev = f0_tokens.device
+        self.G = ops.cached_planes_buffer('G', rows, 512, dev)
+        self.C1, self.CF, self.FH = (ops.cached_planes_buffer(t, rows, 256, dev) for t in ('C1', 'CF', 'FH'))
+        self.F1 = ops.cached_planes_buffer('F1', rows, 128, dev)
+        self.CORR = ops.cached_planes_buffer('CORR', rows, 96, dev)
         fp, _ = ops.nhwc_planes_from([f0_tokens.reshape(rows, 128)])
         proj = torch.empty((rows, 256), dtype=torch.float32, device=f0_tokens.device)
         ops.conv_ex((fp, 128, 0, 128), (b, h, w), self.wts['proj'], (1, 1), 1, (0, 0), 0, out=(proj, 256, 0))
