@@ -124,10 +124,10 @@ class TransformerLayer(nn.Module):
         return source + msg
 
     def _forward_fused(self, ops, source, target, h, w, geom, kv_rotate=0, kv=None, next_kv_weights=None):
-        """``next_kv_weights``: the four k | v projection weights of the NEXT block -- the FFN launch then also returns that
-        block's blocked k | v planes (``ops.ffn_ln_kv``) and the result is ``(tokens, planes)``."""
         """Same layer on the fused HIP path: projections emit attention operand planes, merge + LayerNorm
-        (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``)."""
+        (+ residual) is one kernel, the FFN is one kernel (``um_ffn_fwd``; or two without ``ops.fused_ffn``).
+        ``next_kv_weights``: the four k | v projection weights of the NEXT block -- the FFN launch then also returns that
+        block's blocked k | v planes (``ops.ffn_ln_kv``) and the result is ``(tokens, planes)``."""
         s, l, c = source.shape
         m = s * l
         src = source.reshape(m, c)

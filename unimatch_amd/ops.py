@@ -555,6 +555,8 @@ class HipOps:
         owner = self.workspace_owner if self.workspace_owner is not None else _stream()
         for k in [k for k in cache if isinstance(k[0], tuple) and k[0][:2] == name[:2] and k[0] != name and k[2] == owner]:
             del cache[k]                       # one geometry per owner stays resident (a new input size replaces the old set)
+        if (name, device, owner) not in cache and torch.cuda.is_current_stream_capturing():
+            return self.planes_buffer(rows, ld)  # captured without a warm-up under an owner: the graph's own zero-filled buffer
         return self._split_workspace(name, 2 * (rows + 1) * ld * 2, device)
 
     def conv_weight_planes_from(self, weight):
