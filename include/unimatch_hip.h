@@ -94,7 +94,8 @@ const char* um_last_error_string(void);
 #define UM_V_CONV_PATCH 10    /* conv_patch_kernel (3x3 stride 1, 2-D halo patch)                                       */
 #define UM_V_CONV_ROWS 11     /* conv_rows_kernel (row window shared by the horizontal taps)                            */
 #define UM_V_CONV_GENERIC 12  /* conv_kernel (tap-by-tap implicit GEMM)                                                 */
-#define UM_V_COUNT 13
+#define UM_V_WATTN_W8 13      /* window_attn8_kernel: one 8-wave workgroup per query tile, keys halved inside (big launches) */
+#define UM_V_COUNT 14
 int um_census_enable(int on);
 long um_census_count(int variant);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */

@@ -30,7 +30,12 @@ if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_ke
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcs.log" 2>&1 < /dev/null)
 PMC=$(find /tmp/${TAG}_pmcs -name '*counter_collection.csv' | head -1)
 if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_kernel > "$OUT/${TAG}_pmc_sq.json"; fi
-# then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_pmc_sq.json
+(cd /tmp && timeout 120 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
+    --kernel-trace --output-format csv -d /tmp/${TAG}_pmcl -o p -- \
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmcl.log" 2>&1 < /dev/null)
+PMC=$(find /tmp/${TAG}_pmcl -name '*counter_collection.csv' | head -1)
+if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_kernel > "$OUT/${TAG}_pmc_lds.json"; fi
+# then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_pmc_sq.json gpurun_out/${TAG}_pmc_lds.json
 timeout 150 python tools/bench_configs.py --steps 10 2>&1 | grep cfg > "$OUT/${TAG}_all_configs.txt"
 (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_cfg4" -o p -- \
     python "$R/tools/profile_config.py" gmflow_s2_rr6 4 512 768 > "$OUT/${TAG}_cfg4.log" 2>&1 < /dev/null)

@@ -6,7 +6,10 @@ when the stamp no longer matches the tree.  Run in the build container after the
     python tools/pmc_roofline.py gpurun_out/rNN_pmc_fetch.json gpurun_out/rNN_pmc_write.json [gpurun_out/rNN_pmc_sq.json]
 
 The optional third file is an SQ pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, ...) of the same command: it adds `mfma_busy` =
-SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per kernel, which bench.py quotes beside `frac`.
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per kernel, which bench.py quotes beside `frac`.  An optional
+fourth file is the LDS / VALU pass of tools/collect_counters.sh (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_VALU,
+SQ_ACTIVE_INST_LDS, ...): it adds `lds_busy` = SQ_LDS_IDX_ACTIVE (LDS-array cycles, MI355X_MICROARCH.md LDS section) / (256 CUs x
+GRBM_GUI_ACTIVE / 8) and `valu_busy` = 4 x SQ_ACTIVE_INST_VALU (quad-cycles, MFMA issue included) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte requests as 64 bytes -> read bytes =
 2 x FETCH_SIZE(KiB) x 1024 for the wide coalesced rows these kernels stream; WRITE_SIZE(KiB) x 1024 as is.
@@ -22,7 +25,7 @@ from bench import PMC_FILE, source_stamp  # noqa: E402
 
 KERNELS = {'window_attn_kernel': ['window_attn.hip', 'common.h'], 'gsv3_kernel': ['global_match.hip', 'common.h'],
            'gsv4_kernel': ['global_match.hip', 'common.h'], 'ffn_kernel': ['ffn.hip', 'common.h'], 'kv4_kernel': ['ffn.hip', 'common.h']}
-NUM_SIMDS, NUM_XCDS = 1024, 8
+NUM_SIMDS, NUM_XCDS, NUM_CUS = 1024, 8, 256
 
 
 def main():
@@ -45,6 +48,7 @@ def main():
         files = [a for a in sys.argv[1:] if not a.startswith('--')]
         fetch, write = json.load(open(files[0])), json.load(open(files[1]))
         sq = json.load(open(files[2])) if len(files) > 2 else {}
+        lds = json.load(open(files[3])) if len(files) > 3 else {}
         for k, v in fetch.items():
             base = k.split('<')[0]
             if base not in KERNELS or 'FETCH_SIZE' not in v:
@@ -60,6 +64,14 @@ def main():
                 out[k].update({'mfma_busy': round(busy / (NUM_SIMDS * gui / NUM_XCDS), 4), 'SQ_VALU_MFMA_BUSY_CYCLES': busy,
                                'GRBM_GUI_ACTIVE': gui,
                                **{n: v['mean'] for n, v in c.items() if n not in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')}})
+            c = lds.get(k, {})
+            if 'SQ_LDS_IDX_ACTIVE' in c and 'GRBM_GUI_ACTIVE' in c:
+                gui = c['GRBM_GUI_ACTIVE']['mean'] / NUM_XCDS
+                out[k].update({'lds_busy': round(c['SQ_LDS_IDX_ACTIVE']['mean'] / (NUM_CUS * gui), 4),
+                               'valu_busy': round(4 * c['SQ_ACTIVE_INST_VALU']['mean'] / (NUM_SIMDS * gui), 4),
+                               'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', {}).get('mean'),
+                               **{n: v['mean'] for n, v in c.items() if n in ('SQ_LDS_IDX_ACTIVE', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS',
+                                                                              'SQ_INSTS_LDS')}})
     json.dump(out, open(PMC_FILE, 'w'), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -14,7 +14,7 @@ MODE_FAST = 1
 
 # launch census ids (UM_V_* of the header): which kernel instantiation served a call
 CENSUS = {'wattn_tile': 0, 'wattn_ksplit': 1, 'ffn_tile': 2, 'ffn_hsplit': 3, 'gsv4': 4, 'gsv3': 5, 'k4_mfma': 6, 'k4_valu': 7,
-          'k3_mfma': 8, 'k3_valu': 9, 'conv_patch': 10, 'conv_rows': 11, 'conv_generic': 12}
+          'k3_mfma': 8, 'k3_valu': 9, 'conv_patch': 10, 'conv_rows': 11, 'conv_generic': 12, 'wattn_w8': 13}
 
 _c_int, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 

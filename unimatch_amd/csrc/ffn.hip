@@ -73,6 +73,16 @@ struct FfnArgs {
     Kv4Args kv;
 };
 
+// the same with the LDS destination as an ADDRESS (an SGPR value): a flat pointer into the LDS array costs an address-space cast
+// with its null check (s_add_u32 / s_addc_u32 / s_cmp_lg_u64 / s_cselect_b32) per statement; base address + constant costs one s_add
+__device__ __forceinline__ void ffn_dma16_at(const void* base, unsigned byte_off, unsigned lds_addr) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);         // (uniform already; folds away when the compiler can prove it)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(lds_addr)
+                 : "memory");
+}
 __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(
         (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds_dst);
@@ -381,6 +391,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     if (tracing) trace_buf[24 * 8] = __builtin_amdgcn_s_memtime();
 #endif
     // the same six statements one at a time (UM_FFN_ORDER 1: they are issued in the gaps of the phase-A MFMAs)
+    // (LDS destinations as addresses: base of the array + this wave's kilobyte, in an SGPR, + a compile-time constant)
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)lds) + (unsigned)wave * 1024u;
     auto dma_piece = [&](int k, int jw1, int jw2, int slot) {      // k = 0..3: W1 (i = k >> 1, plane k & 1), 4..5: W2 plane k - 4
         if (k < 4) {
             const int i = k >> 1, pl = k & 1;
@@ -388,13 +401,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             const int blk = 8 * i + wave;
             const int r = 2 * blk + half, c = tl ^ r;
             const unsigned off = (unsigned)((((long)(32 * (sbase + jw1) + r)) * 256 + 8 * c) * 2);
-            ffn_dma16(a.w1 + pl * a.w1_plane_stride, off, lds + L::W1_OFF + slot * L::W1S + pl * L::W1P + blk * 1024);
+            ffn_dma16_at(a.w1 + pl * a.w1_plane_stride, off, lds_wave + (unsigned)(L::W1_OFF + slot * L::W1S + pl * L::W1P + 8 * i * 1024));
         } else {
             const int pl = k - 4;
             if (pl >= NS) return;
             const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
             const unsigned off = (unsigned)((((long)r) * a.hid + 32 * (sbase + jw2) + 8 * c) * 2);
-            ffn_dma16(a.w2 + pl * a.w2_plane_stride, off, lds + L::W2_OFF + slot * L::W2S + pl * L::W2P + wave * 1024);
+            ffn_dma16_at(a.w2 + pl * a.w2_plane_stride, off, lds_wave + (unsigned)(L::W2_OFF + slot * L::W2S + pl * L::W2P));
         }
     };
 
@@ -452,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
         const int r = 32 * ot + tl;
-        boff[ot] = r * 64 + (((2 * role + half) ^ ((r >> 2) & 3)) << 4);
+        boff[ot] = L::W2_OFF + r * 64 + (((2 * role + half) ^ ((r >> 2) & 3)) << 4);   // (carries the ring's base: beyond the 64 KB a DS
+                                                                                         // instruction's immediate offset reaches)
     }
     unsigned char* xb_out = lds + L::XB_OFF + wave * L::XB + lane * 16;
     const unsigned char* xb_in = lds + L::XB_OFF + (wave ^ 4) * L::XB + lane * 16;
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         constexpr int NGELU = 4 * UM_GELU_STAGES, NSTAGE = NGELU + 4;
         const int slot = i & 1;
         const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
-        const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
+        const unsigned char* w2s = lds + (slot ^ 1) * L::W2S;                 // (+ W2_OFF inside boff)     // W2(i-1)
         UM_FSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(i+1), W2(i-1): this thread's pieces have landed
         UM_FSTAMP(1);
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     //     MFMA pipe :  phase A of slice i+1 (24 MFMAs)  then  phase B of slice i-1 (12, fragments built last iteration)
     //     gaps      :  GELU of slice i + its H^T fragments (as before, one share per MFMA); the LDS-DMA statements of W1(i+2) and
     //                  W2(i) behind the first phase-A MFMAs; the accumulator hand-over (add, send) behind the first phase-B MFMAs
-    auto iteration1 = [&](auto has_a_tag, auto has_b_tag, auto dma1_tag, int i) {
+    auto iteration1 = [&](auto has_a_tag, auto has_b_tag, auto dma1_tag, auto slot_tag, int i) {
         constexpr bool HAS_A = decltype(has_a_tag)::value && !(UM_FFN_ABL & 4);
         constexpr bool HAS_B = decltype(has_b_tag)::value && !(UM_FFN_ABL & 8);
         constexpr bool DMA1 = decltype(dma1_tag)::value;           // W1(i+2) exists
@@ -686,9 +700,12 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         constexpr int MFB = (NS == 2 && UM_FFN_H1) ? 2 : MF;
         constexpr int NA = HAS_A ? 8 * MF : 0, NB = HAS_B ? 4 * MFB : 0, NMFMA = NA + NB;
         constexpr int NGELU = 4 * UM_GELU_STAGES, NSTAGE = NGELU + 4;
-        const int slot = i & 1;
+        // ring slot = i & 1, at COMPILE time (round 5: the loop runs two slices per trip): every fragment read, exchange access and
+        // LDS-DMA destination of the slice is register + immediate -- with the slot in a register the slice carried 16 v_add_u32 and
+        // ~25 scalar instructions of slot arithmetic (SQ_INSTS_SALU / SQ_INSTS_MFMA = 1.66, profiles/r05_pmc_bounds.json)
+        const int slot = slot_tag;                                // (an integral_constant in the paired loop, an int around it)
         const unsigned char* w1s = lds + L::W1_OFF + (slot ^ 1) * L::W1S;     // W1(i+1)
-        const unsigned char* w2s = lds + L::W2_OFF + (slot ^ 1) * L::W2S;     // W2(i-1)
+        const unsigned char* w2s = lds + (slot ^ 1) * L::W2S;                 // (+ W2_OFF inside boff)     // W2(i-1)
         UM_FSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W1(i+1), W2(i-1): this thread's pieces have landed
         UM_FSTAMP(1);
@@ -866,19 +883,33 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     if (UM_FFN_ORDER == 1) {
         using Y = std::true_type;
         using N = std::false_type;
-        if (2 < nslice) iteration1(Y{}, N{}, Y{}, 0);
-        else iteration1(Y{}, N{}, N{}, 0);
-        int i = 1;
-        for (; i + 2 < nslice; ++i) iteration1(Y{}, Y{}, Y{}, i);
-        for (; i + 1 < nslice; ++i) iteration1(Y{}, Y{}, N{}, i);
-        iteration1(N{}, Y{}, N{}, nslice - 1);
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if ((nslice & 1) == 0 && nslice >= 4) {                    // every shipped geometry: hid = 1024 -> 32 / 16 / 8 slices
+            iteration1(Y{}, N{}, Y{}, S0{}, 0);
+            int i = 1;
+            for (; i + 4 < nslice; i += 2) {                       // slices 1 .. nslice - 4 in pairs (odd, even)
+                iteration1(Y{}, Y{}, Y{}, S1{}, i);
+                iteration1(Y{}, Y{}, Y{}, S0{}, i + 1);
+            }
+            iteration1(Y{}, Y{}, Y{}, S1{}, nslice - 3);
+            iteration1(Y{}, Y{}, N{}, S0{}, nslice - 2);
+            iteration1(N{}, Y{}, N{}, S1{}, nslice - 1);
+        } else {                                                    // any other slice count: the slot in a register
+            if (2 < nslice) iteration1(Y{}, N{}, Y{}, 0, 0);
+            else iteration1(Y{}, N{}, N{}, 0, 0);
+            int i = 1;
+            for (; i + 2 < nslice; ++i) iteration1(Y{}, Y{}, Y{}, i & 1, i);
+            for (; i + 1 < nslice; ++i) iteration1(Y{}, Y{}, N{}, i & 1, i);
+            iteration1(N{}, Y{}, N{}, (nslice - 1) & 1, nslice - 1);
+        }
     } else {
         iteration(std::true_type{}, std::false_type{}, 0);
         for (int i = 1; i + 1 < nslice; ++i) iteration(std::true_type{}, std::true_type{}, i);
         iteration(std::false_type{}, std::true_type{}, nslice - 1);
     }
     {   // phase B of the last slice
-        const unsigned char* w2s = lds + L::W2_OFF + ((nslice - 1) & 1) * L::W2S;
+        const unsigned char* w2s = lds + ((nslice - 1) & 1) * L::W2S;          // (+ W2_OFF inside boff)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (!(UM_FFN_ABL & 8)) {
