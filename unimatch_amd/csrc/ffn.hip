@@ -119,8 +119,23 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 #ifndef UM_FFN_DMA_ASYM
 #define UM_FFN_DMA_ASYM 0
 #endif
+// Diagnostic builds: -DUM_FFN_NT=1 non-temporal loads of the token rows (x | y, residual), 2: ... and non-temporal stores of the output --
+// whether keeping the streamed rows out of the XCD's L2 saves the weight slices' re-fetches (profiles/r05_ffn_overfetch.txt)
+#ifndef UM_FFN_NT
+#define UM_FFN_NT 0
+#endif
+#if UM_FFN_NT >= 1
+#define UM_FFN_LD(p) __builtin_nontemporal_load(p)
+#else
+#define UM_FFN_LD(p) (*(p))
+#endif
+#if UM_FFN_NT >= 2
+#define UM_FFN_ST(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define UM_FFN_ST(p, v) (*(p) = (v))
+#endif
 #ifndef UM_FFN_ABL
-#define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange
+#define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange, 32 residual read
 #endif
 // erf-GELU on two values at once, branch free and in ONE piece (ocml's erff is two divergent branches per element, ~40 VALU
 // slots and a scheduling wall between every element; the two-piece minimax erff this kernel used in round 1 evaluated both
@@ -437,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         const float* src = (role ? a.y : a.x) + (long)min(tok, a.M - 1) * 128 + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            const f32x4 v0 = UM_FFN_LD(reinterpret_cast<const f32x4*>(src + 16 * ks));
+            const f32x4 v1 = UM_FFN_LD(reinterpret_cast<const f32x4*>(src + 16 * ks + 4));
             const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
             xf[0][ks] = __builtin_bit_cast(i16x8, h);
             if (NS == 2) {
@@ -908,10 +923,20 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         for (int i = 1; i + 1 < nslice; ++i) iteration(std::true_type{}, std::true_type{}, i);
         iteration(std::false_type{}, std::true_type{}, nslice - 1);
     }
+    // The residual rows (this lane's 64 fp32 values of x) are requested HERE, a whole exchange + LayerNorm ahead of their use: the token
+    // operand's 64 registers are dead since the last phase A.  (They are a second read of x: 50 MB of the launch's 182 MB of fabric reads
+    // at config 2 -- the tile left the XCD's L2 ~100 us ago; profiles/r05_ffn_overfetch.txt.)
+    f32x4 rr[16];
     {   // phase B of the last slice
         const unsigned char* w2s = lds + ((nslice - 1) & 1) * L::W2S;          // (+ W2_OFF inside boff)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (role == 0) {
+            const float* res = a.x + (long)min(tok, a.M - 1) * 128 + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                rr[q] = (UM_FFN_ABL & 32) ? f32x4{0.f, 0.f, 0.f, 0.f} : UM_FFN_LD(reinterpret_cast<const f32x4*>(res + 8 * q));
+        }
         if (!(UM_FFN_ABL & 8)) {
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) {
@@ -1027,7 +1052,6 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         // lane holds, for its token, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot)
         const int tokc = min(tok, a.M - 1);                         // (KV4: rows past M are computed on a valid row and never stored)
         float* dst = a.out + (long)tokc * 128 + 4 * half;
-        const float* res = a.x + (long)tokc * 128 + 4 * half;
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -1035,11 +1059,10 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 const int n = 32 * ot + 8 * g;
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + n + 4 * half);
                 const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + n + 4 * half);
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(res + n);
                 f32x4 yv;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) yv[i] = (o[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i] + rr[i];
-                if (tok < a.M) *reinterpret_cast<f32x4*>(dst + n) = yv;
+                for (int i = 0; i < 4; ++i) yv[i] = (o[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i] + rr[4 * ot + g][i];
+                if (tok < a.M) UM_FFN_ST(reinterpret_cast<f32x4*>(dst + n), yv);
                 if constexpr (KV4) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = yv[i];
