@@ -183,13 +183,29 @@ KERNEL_NAMES = ['window_attn', 'global_softmax (gsv3/gsv4)', 'split_planes', 'lo
                 'depth_corr', 'linear', 'instance_norm / nhwc', 'convex_upsample / warp', 'ffn', 'conv']
 
 
+def run_as_launcher(argv, gpus, need_gpus=True):
+    """`python bench.py --gpus N` without a launcher: start the N ranks and pass rank 0's line on ONLY when every rank exited 0.
+    A job in which any rank failed prints a line with ``value: null``, the exit code and the tail of the ranks' stderr instead --
+    a failed rank can never produce a number.  Returns the exit code."""
+    from unimatch_amd.dist import launch_ranks
+    rc, out, err = launch_ranks(os.path.abspath(__file__), argv, gpus, need_gpus=need_gpus, capture=True)
+    sys.stderr.write(err)
+    if rc != 0:
+        print(json.dumps({'metric': 'image-pairs/sec', 'value': None, 'unit': 'pairs/s', 'n_gpus': gpus, 'higher_is_better': True,
+                          'error': f'a rank of the {gpus}-rank job exited with code {rc}: no measurement', 'exit_code': rc,
+                          'stderr_tail': err[-6000:]}), flush=True)
+        return rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse()
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher (fails loudly when the node has fewer than N GPUs)
-        from unimatch_amd.dist import launch_ranks
-        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(run_as_launcher(sys.argv[1:], args.gpus))
     world = int(env_world or '1')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

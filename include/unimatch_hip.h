@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define UM_VERSION 200
+#define UM_VERSION 210
 
 #define UM_MODE_EXACT 0
 #define UM_MODE_FAST 1

@@ -149,12 +149,53 @@ def test_id_file_readers_skip_records_of_another_job(tmp_path):
     from unimatch_amd import _abi
     lib = _abi.load()
     path = tmp_path / 'id'
-    path.write_bytes(b'UMRCCL02' + struct.pack('<iiq', 2, 1234, int(time.time())) + bytes(128))
+    path.write_bytes(b'UMRCCL03' + struct.pack('<iiq', 2, 1234, int(time.time())) + bytes(128))
     comm = ctypes.c_void_p()
     t0 = time.time()
     rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321)
     assert rc == -5 and b'nonce 4321' in lib.um_last_error_string() and time.time() - t0 < 10
     assert path.exists()                                    # a reader never removes the record
+    assert not (tmp_path / 'id.ack1').exists()              # ... and does not acknowledge a record that is not its job's
+    # a record of the round-4 layout (magic 02) is not taken either, whatever its nonce
+    path.write_bytes(b'UMRCCL02' + struct.pack('<iiq', 2, 4321, int(time.time())) + bytes(128))
+    assert lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321) == -5
+
+
+def test_id_file_reader_acknowledges_and_gives_up_without_the_go(tmp_path):
+    """The three-step rendezvous (publish / ack / go): a reader that finds ITS job's record acknowledges it and then waits for rank
+    0's go; when another rank never shows up rank 0 never gives it, and the reader returns UM_ERR_COLLECTIVE after the timeout --
+    nobody is left inside ncclCommInitRank."""
+    import ctypes
+    import struct
+    import time
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    path = tmp_path / 'id'
+    path.write_bytes(b'UMRCCL03' + struct.pack('<iiq', 3, 77, int(time.time())) + bytes(128))
+    comm = ctypes.c_void_p()
+    t0 = time.time()
+    rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 2, 3, 1, 77)
+    assert rc == -5 and b"rank 0's go" in lib.um_last_error_string() and time.time() - t0 < 10
+    assert not comm.value and not (tmp_path / 'id.ack2').exists()       # its acknowledgement is withdrawn
+
+
+def test_job_nonce_is_shared_by_ranks_with_different_parents(tmp_path, monkeypatch):
+    """The nonce is a function of what the ranks share (UM_RCCL_NONCE, or the rendezvous address and the id-file path) and of nothing
+    else: two ranks started by different parent processes compute the same value (getppid made them disagree)."""
+    import subprocess
+    import sys
+    from unimatch_amd import dist as umd
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29511')
+    monkeypatch.delenv('UM_RCCL_NONCE', raising=False)
+    here = umd.job_nonce(str(tmp_path / 'id'))
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from unimatch_amd import dist; print(dist.job_nonce({str(tmp_path / 'id')!r}))"
+    # the same question from a grandchild (another parent pid) and through a shell
+    other = subprocess.run([sys.executable, '-c', f"import subprocess, sys; print(subprocess.run([sys.executable, '-c', {code!r}], "
+                            "capture_output=True, text=True).stdout)"], capture_output=True, text=True, env=dict(os.environ)).stdout
+    assert int(other.strip()) == here and here != umd.job_nonce(str(tmp_path / 'other'))
+    monkeypatch.setenv('UM_RCCL_NONCE', '12345')
+    assert umd.job_nonce('anything') == 12345
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='exercises the no-GPU fallback agreement')
@@ -207,6 +248,34 @@ def test_launcher_starts_every_rank(tmp_path):
     assert launch_ranks(str(script), ['hello'], 2, need_gpus=False) == 0
     for r in range(2):
         assert (tmp_path / f'rank{r}.txt').read_text() == '2 3 hello'
+
+
+def test_launcher_reports_a_failed_rank(tmp_path):
+    """One rank exiting non-zero makes the whole launch non-zero, and its stderr reaches the caller (``capture``)."""
+    from unimatch_amd.dist import launch_ranks
+    script = tmp_path / 'ranks.py'
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        if os.environ['RANK'] == '1':
+            sys.stderr.write('rank 1: the GPU fell off the bus\\n')
+            sys.exit(3)
+        print('{"value": 123.0}')
+    """))
+    rc, out, err = launch_ranks(str(script), [], 2, need_gpus=False, capture=True)
+    assert rc != 0 and 'the GPU fell off the bus' in err
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='drives the ranks into their own no-GPU error')
+def test_bench_launcher_never_prints_a_number_when_a_rank_failed(capsys):
+    """`python bench.py --gpus 2` as its own launcher: when a rank exits non-zero (here: every rank finds no GPU) the parent prints a
+    line with value null, the exit code and the ranks' stderr -- never rank 0's number."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    rc = bench.run_as_launcher(['--gpus', '2', '--steps', '1', '--warmup', '0'], 2, need_gpus=False)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc != 0 and line['value'] is None and line['exit_code'] == rc and line['n_gpus'] == 2
+    assert 'needs GPU' in line['stderr_tail']
 
 
 @pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason='needs a node with fewer than 2 GPUs')

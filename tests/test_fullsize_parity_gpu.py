@@ -30,7 +30,12 @@ def legs():
     # CPU legs computed elsewhere (tools/parity_fullsize.py --stage cpu --cache gpurun_cache/parity, e.g. in the build container)
     # are picked up when the directory travelled with the tree; otherwise everything is computed here
     cache = os.path.join(ROOT, 'gpurun_cache', 'parity')
-    pool = pf.CpuLegs(workers=12, threads=8, cache=cache if os.path.isdir(cache) else None)
+    # sized by the host (UM_PARITY_WORKERS / UM_PARITY_THREADS override): up to 12 worker processes of 8 threads on the 256-core
+    # driver box, fewer on a small CI host instead of oversubscribing it
+    cores = os.cpu_count() or 8
+    threads = int(os.environ.get('UM_PARITY_THREADS', max(1, min(8, cores // 4))))
+    workers = int(os.environ.get('UM_PARITY_WORKERS', max(1, min(12, cores // threads))))
+    pool = pf.CpuLegs(workers=workers, threads=threads, cache=cache if os.path.isdir(cache) else None)
     # queue every sample of every case up front: the pool works through them while the GPU tests run
     pool.submit([(cfg, which, KIND, SEED, i) for cfg, which in CASES for i in range(pf.RUNS[cfg][3])])
     yield pool

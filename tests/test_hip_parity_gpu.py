@@ -862,6 +862,16 @@ def test_nhwc_update_block_matches_module(ops, fd, hw):
     upd.begin(f0.to(DEV), b, h, w)
     mask3, delta3 = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
     assert torch.equal(delta3, delta) and torch.equal(mask3, mask)
+    # the hoisted gate share must cover every pixel row: a short addend is an error, not an out-of-bounds read
+    with pytest.raises(ValueError, match='addend must be'):
+        ops.conv_gru(1, (hst.G, 512, 256, 128), (b, h, w), hst.wts['zr1v'], (1, 5), (0, 2), hst.H, (hst.G, 512, 384), z_out=hst.ZR,
+                     addend=hst.P['zr1'][:-1].contiguous())
+    # explicit release of the cached activation planes (~590 MB per stream at config 4): gone from the cache, rebuilt on demand
+    ops.release_cached_planes()
+    assert not [k for k in ops._split_ws if isinstance(k[0], tuple)]
+    upd.begin(f0.to(DEV), b, h, w)
+    mask4, delta4 = upd.iterate(ori0.to(DEV), ori1.to(DEV), disp.to(DEV).contiguous(), flow.to(DEV), True)
+    assert torch.equal(delta4, delta) and torch.equal(mask4, mask)
 
 
 @pytest.mark.parametrize('bhw,normalize', [((2, 64, 96), True), ((1, 37, 51), False), ((3, 16, 32), True)])
@@ -1464,13 +1474,26 @@ def test_graph_capture_owns_its_split_workspaces():
         for key, buf in ws.items():
             if isinstance(key[0], str):                                      # the counters (not the refinement's plane buffers)
                 assert int(buf[:64].count_nonzero()) == 0
-    fresh = HipOps('exact')                                                  # first-time request inside a capture: refused
+    # first-time request inside a capture (a user's own torch.cuda.graph, no warm-up under an owner): a capture-private zeroed
+    # buffer that is NOT cached -- no later launch can meet counters an aborted capture left behind (raising here
+    # turned such captures into a permanent eager fallback)
+    fresh = HipOps('exact')
     graph = torch.cuda.CUDAGraph()
     x = rnd(900, 2240, 128).to(DEV)
-    with pytest.raises(RuntimeError, match='inside a stream capture'):
-        with torch.cuda.graph(graph):
-            fresh._split_workspace('_ffn_ws', 1 << 20, x.device)
+    with torch.cuda.graph(graph):
+        ws = fresh._split_workspace('_ffn_ws', 1 << 20, x.device)
+        probe = ws[:64].clone()
+    graph.replay()
     torch.cuda.synchronize()
+    assert int(probe.count_nonzero()) == 0 and not fresh.__dict__.get('_split_ws')
+    # a graph around a WRAPPER of the model (ShardedUniMatch at world size 1) finds the HipOps through it: its workspaces are
+    # owned by the graph exactly as above, and the capture succeeds (no eager fallback)
+    from unimatch_amd.dist import ShardedUniMatch
+    g3 = GraphedUniMatch(ShardedUniMatch(model, rank=0, world=1))
+    c = g3(i0, i1, **fk)['flow_preds'][0]
+    entry = next(iter(g3._graphs.values()))
+    assert entry is not False and entry['workspaces'] and torch.equal(c, eager)
+    assert set(ops._split_ws) == eager_keys and ops.workspace_owner is None
 
 
 def test_sharded_model_through_the_rccl_gather_at_world_one():

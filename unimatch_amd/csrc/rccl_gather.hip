@@ -105,14 +105,19 @@ extern "C" int um_comm_init_rank(void** comm_out, const void* id, int rank, int 
     return 0;
 }
 
-// File bootstrap: rank 0 removes whatever is at `path`, writes {magic, world, wall-clock stamp, id} to `<path>.tmp` and renames it
-// to `path` (atomic on one filesystem); the other ranks poll for a record with the right magic and world that is younger than
-// UM_ID_FILE_MAX_AGE seconds (a file left behind by a crashed job of another day is ignored instead of handing out a dead id),
-// and rank 0 deletes the file once ncclCommInitRank has returned, i.e. after every rank has joined.  Two jobs must not share a
-// path at the same time: key it by job (unimatch_amd.dist.job_id_file: rendezvous port + launcher pid).  A job that crashed
-// between publish and unlink leaves a record that is still "fresh" for UM_ID_FILE_MAX_AGE seconds: um_comm_init_file_nonce
-// stores a caller-chosen per-job nonce in the record and its readers skip records of another nonce, so a relaunch under the
-// same path never joins the dead id (um_comm_init_file = nonce 0 on both sides).
+// File bootstrap, three steps so that NO rank enters ncclCommInitRank (which cannot time out) unless all of them will:
+//   1. publish   rank 0 removes whatever is at `path`, writes {magic, world, nonce, wall-clock stamp, id} to `<path>.tmp` and renames it
+//                to `path` (atomic on one filesystem);
+//   2. ack       every other rank polls for a record with the right magic, world and NONCE that is younger than UM_ID_FILE_MAX_AGE
+//                seconds, then creates `<path>.ack<rank>`; rank 0 polls for the world - 1 acks;
+//   3. go        rank 0 creates `<path>.go`; the others poll for it; everybody calls ncclCommInitRank; rank 0 removes the files.
+// Every wait honours `timeout_seconds` on EVERY rank, rank 0 included (round 4's protocol left rank 0 inside ncclCommInitRank for ever
+// when a reader never found its record): a rank that is missing, or that disagrees about the nonce, makes all ranks return
+// UM_ERR_COLLECTIVE after the timeout instead of hanging one of them.
+// Two jobs must not share a path at the same time: key it by job.  The nonce guards the one case a path cannot: a job that crashed
+// between publish and clean-up leaves a record that is still "fresh" for UM_ID_FILE_MAX_AGE seconds; a relaunch under the same path
+// with another nonce never joins the dead id.  The nonce must be derived from values EVERY rank of the job shares (the path itself,
+// MASTER_ADDR:MASTER_PORT, an explicit UM_RCCL_NONCE) -- never from a pid (unimatch_amd.dist.job_nonce).
 #define UM_ID_FILE_MAX_AGE 600
 namespace {
 struct IdRecord {
@@ -122,7 +127,16 @@ struct IdRecord {
     long long stamp;
     unsigned char id[UM_COMM_ID_BYTES];
 };
-const char kIdMagic[8] = {'U', 'M', 'R', 'C', 'C', 'L', '0', '2'};
+const char kIdMagic[8] = {'U', 'M', 'R', 'C', 'C', 'L', '0', '3'};      // 03: the ack / go rendezvous (02: publish + poll only)
+
+bool file_exists(const char* p) { return access(p, F_OK) == 0; }
+bool touch(const char* p) {
+    FILE* f = fopen(p, "wb");
+    if (!f) return false;
+    fclose(f);
+    return true;
+}
+bool expired(time_t t0, int timeout_seconds) { return timeout_seconds >= 0 && time(nullptr) - t0 > timeout_seconds; }
 }  // namespace
 
 extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int rank, int world, int timeout_seconds, int nonce);
@@ -140,6 +154,15 @@ extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int ra
         um_set_error("um_comm_init_file: path longer than 1000 bytes");
         return UM_ERR_BAD_ARG;
     }
+    char aux[1024 + 32];
+    auto ack_path = [&](int r) { snprintf(aux, sizeof(aux), "%s.ack%d", path, r); return aux; };
+    auto go_path = [&]() { snprintf(aux, sizeof(aux), "%s.go", path); return aux; };
+    auto cleanup = [&]() {                                          // rank 0 only
+        (void)unlink(path);
+        (void)unlink(go_path());
+        for (int r = 1; r < world; ++r) (void)unlink(ack_path(r));
+    };
+    const time_t t0 = time(nullptr);
     IdRecord rec;
     if (rank == 0) {
         memset(&rec, 0, sizeof(rec));
@@ -148,7 +171,7 @@ extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int ra
         rec.nonce = nonce;
         rec.stamp = (long long)time(nullptr);
         if (int e = um_comm_unique_id(rec.id)) return e;
-        (void)unlink(path);                                         // a leftover of an earlier job under the same key
+        cleanup();                                                  // leftovers of an earlier job under the same key
         char tmp[1024 + 8];
         snprintf(tmp, sizeof(tmp), "%s.tmp", path);
         FILE* f = fopen(tmp, "wb");
@@ -156,8 +179,23 @@ extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int ra
             um_set_error("um_comm_init_file: cannot publish the unique id at %s", path);
             return UM_ERR_COLLECTIVE;
         }
+        for (int r = 1; r < world; ++r) {
+            while (!file_exists(ack_path(r))) {
+                if (expired(t0, timeout_seconds)) {
+                    um_set_error("um_comm_init_file: rank 0 waited %d s for rank %d to acknowledge the id record (nonce %d) at %s -- is that rank "
+                                 "running, on the same filesystem, with the same nonce?", timeout_seconds, r, nonce, path);
+                    cleanup();
+                    return UM_ERR_COLLECTIVE;
+                }
+                usleep(20000);
+            }
+        }
+        if (!touch(go_path())) {
+            um_set_error("um_comm_init_file: cannot create %s.go", path);
+            cleanup();
+            return UM_ERR_COLLECTIVE;
+        }
     } else {
-        const time_t t0 = time(nullptr);
         for (;;) {
             FILE* f = fopen(path, "rb");
             if (f) {
@@ -167,16 +205,29 @@ extern "C" int um_comm_init_file_nonce(void** comm_out, const char* path, int ra
                     rec.nonce == nonce && (long long)time(nullptr) - rec.stamp <= UM_ID_FILE_MAX_AGE)
                     break;
             }
-            if (timeout_seconds >= 0 && time(nullptr) - t0 > timeout_seconds) {
+            if (expired(t0, timeout_seconds)) {
                 um_set_error("um_comm_init_file: rank %d waited %d s for a fresh id record of this job (nonce %d) at %s", rank, timeout_seconds,
                              nonce, path);
                 return UM_ERR_COLLECTIVE;
             }
             usleep(20000);
         }
+        if (!touch(ack_path(rank))) {
+            um_set_error("um_comm_init_file: rank %d cannot create %s.ack%d", rank, path, rank);
+            return UM_ERR_COLLECTIVE;
+        }
+        while (!file_exists(go_path())) {
+            if (expired(t0, timeout_seconds)) {
+                um_set_error("um_comm_init_file: rank %d waited %d s for rank 0's go (another rank never acknowledged) at %s", rank,
+                             timeout_seconds, path);
+                (void)unlink(ack_path(rank));
+                return UM_ERR_COLLECTIVE;
+            }
+            usleep(20000);
+        }
     }
     const int e = um_comm_init_rank(comm_out, rec.id, rank, world);
-    if (rank == 0) (void)unlink(path);                              // every rank has joined (or the bootstrap failed): single use
+    if (rank == 0) cleanup();                                       // every rank has joined (or the bootstrap failed): single use
     return e;
 }
 

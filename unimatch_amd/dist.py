@@ -52,10 +52,11 @@ class RcclGather:
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):                       # ncclCommInitRank binds the current device
             if id_file:
-                # the record carries a per-job nonce (rendezvous port + launcher pid): a record a crashed job left at the same
-                # path within the freshness window is not this job's and is ignored by the readers
+                # the record carries a per-job nonce derived from values every rank shares (UM_RCCL_NONCE, else the rendezvous
+                # address and the path itself): a record a crashed job left at the same path within the freshness window is not
+                # this job's and is ignored by the readers.  Every rank -- rank 0 included -- gives up after `timeout` seconds.
                 code = self.lib.um_comm_init_file_nonce(ctypes.byref(self.comm), os.fsencode(id_file), rank, world, timeout,
-                                                        job_nonce())
+                                                        job_nonce(id_file))
             else:
                 # Rank 0 ALWAYS broadcasts -- the id, or the reason it could not get one -- so that every rank passes through
                 # the same collective and then raises the same error (a rank-0-only exception in front of the broadcast left
@@ -197,11 +198,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(script, script_args, nproc, need_gpus=True, env=None):
+def launch_ranks(script, script_args, nproc, need_gpus=True, env=None, capture=False):
     """Run ``script`` as ``nproc`` ranks of one node (what ``python bench.py --gpus N`` does when it was not started
     by a launcher): ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``.
     Fails loudly -- never silently measures fewer GPUs -- when the node has fewer than ``nproc`` GPUs.
-    Returns the launcher's exit code."""
+    Returns the launcher's exit code (non-zero as soon as ANY rank exits non-zero: torch.distributed.run tears the others down);
+    with ``capture`` it returns ``(exit code, stdout, stderr)`` of the whole job instead of letting the ranks write to the caller's
+    streams, so that the caller can refuse to pass on a result line of a job in which a rank failed."""
     if need_gpus:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < nproc:
@@ -210,24 +213,31 @@ def launch_ranks(script, script_args, nproc, need_gpus=True, env=None):
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script] + list(script_args)
     e = dict(os.environ if env is None else env)
     e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')                 # dmabuf IPC only on these hosts (RCCL needs it)
+    if capture:
+        done = subprocess.run(cmd, env=e, capture_output=True, text=True)
+        return done.returncode, done.stdout, done.stderr
     return subprocess.call(cmd, env=e)
 
 
 def job_id_file(port=None):
-    """A job-unique path for ``um_comm_init_file`` (rendezvous port + launcher pid), for callers that bootstrap the
-    communicator without ``torch.distributed`` (export it as UM_RCCL_ID_FILE; ``launch_ranks`` itself never needs one: its ranks
-    bootstrap through the launcher's process group)."""
+    """A job-unique path for ``um_comm_init_file`` (rendezvous port + the CALLER's parent pid), for a launcher that bootstraps the
+    communicator without ``torch.distributed``: compute it ONCE in the launcher and export it to every rank as UM_RCCL_ID_FILE
+    (ranks must not call this themselves unless they share a parent).  ``launch_ranks`` never needs one: its ranks bootstrap through
+    the launcher's process group."""
     import tempfile
     port = port if port is not None else os.environ.get('MASTER_PORT', '0')
     return os.path.join(tempfile.gettempdir(), f'um_rccl_id_{port}_{os.getppid()}')
 
 
-def job_nonce():
-    """31-bit tag shared by the ranks of ONE launch (same rendezvous port, same launcher process) and by no other job on the
-    node at the same time: stored in the id-file record, checked by its readers (UM_RCCL_NONCE overrides)."""
+def job_nonce(id_file=None):
+    """31-bit tag stored in the id-file record and checked by its readers, so that a relaunch never joins the record a crashed job
+    left under the same path.  Built ONLY from values every rank of a job shares however the ranks were started (separate shells,
+    per-node agents, a scheduler): ``UM_RCCL_NONCE`` when set (export a fresh value per launch for the strongest guarantee), else a
+    hash of MASTER_ADDR:MASTER_PORT and the id-file path.  (Round 4 mixed in ``os.getppid()``: ranks with different parents then
+    disagreed and the bootstrap timed out.)"""
     if os.environ.get('UM_RCCL_NONCE'):
         return int(os.environ['UM_RCCL_NONCE']) & 0x7fffffff
-    key = f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '0')}:{os.getppid()}"
+    key = f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '0')}:{os.path.abspath(id_file) if id_file else ''}"
     return (zlib.crc32(key.encode()) & 0x7fffffff) or 1
 
 

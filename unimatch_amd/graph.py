@@ -19,6 +19,19 @@ def _freeze(v):
     return v
 
 
+def _find_ops(model):
+    """The ``HipOps`` of a model, looked for through wrappers (``ShardedUniMatch(model)``, ``DistributedDataParallel`` ...: the
+    attributes ``model`` / ``module``), so that the owner token reaches the instance whose workspaces the capture bakes in."""
+    seen = set()
+    while model is not None and id(model) not in seen:
+        seen.add(id(model))
+        ops = getattr(model, 'ops', None)
+        if ops is not None and hasattr(ops, 'claim_workspaces'):
+            return ops
+        model = getattr(model, 'model', None) or getattr(model, 'module', None)
+    return None
+
+
 class GraphedUniMatch(torch.nn.Module):
     def __init__(self, model, warmup=2, clone_output=True):
         super().__init__()
@@ -34,7 +47,7 @@ class GraphedUniMatch(torch.nn.Module):
         # the duration of warm-up + capture: the eager warm-up allocates and zeroes them OUTSIDE the capture, the capture bakes
         # in the same addresses, and this graph then owns them alone (ops.claim_workspaces) -- two graphs replayed concurrently
         # share no counter, and an aborted capture's buffers are dropped with the token instead of being reused.
-        ops = getattr(self.model, 'ops', None)
+        ops = _find_ops(self.model)
         token = object()
         if ops is not None and hasattr(ops, 'claim_workspaces'):
             ops.workspace_owner = token

@@ -322,10 +322,12 @@ class HipOps:
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes or (isinstance(name, tuple) and buf.numel() != nbytes):
             if torch.cuda.is_current_stream_capturing():
-                # would come from the graph's private pool and only be zeroed by a memset NODE: refuse instead of baking in a
-                # buffer whose counters are garbage if this capture aborts
-                raise RuntimeError(f'{name}: split workspace requested for the first time inside a stream capture; run the '
-                                   'same call eagerly first (GraphedUniMatch warms up under its workspace owner token)')
+                # First request INSIDE a capture (a user's own torch.cuda.graph around the model, or a wrapper GraphedUniMatch could
+                # not install its owner token through): a capture-PRIVATE buffer -- allocated from the graph's pool, zeroed by a memset
+                # node that replays with the graph, referenced by this capture only and never cached, so no later launch can meet
+                # counters an aborted capture left behind.  (Round 4 raised here, which turned such captures into a permanent eager
+                # fallback.)
+                return torch.zeros(nbytes, dtype=torch.uint8, device=device)
             buf = cache[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         return buf
 
@@ -553,11 +555,21 @@ class HipOps:
         name = ('planes', tag, rows, ld)
         cache = self.__dict__.setdefault('_split_ws', {})
         owner = self.workspace_owner if self.workspace_owner is not None else _stream()
-        for k in [k for k in cache if isinstance(k[0], tuple) and k[0][:2] == name[:2] and k[0] != name and k[2] == owner]:
-            del cache[k]                       # one geometry per owner stays resident (a new input size replaces the old set)
+        device = torch.device(device)
+        for k in [k for k in cache if isinstance(k[0], tuple) and k[0][:2] == name[:2] and k[0] != name and k[2] == owner
+                  and torch.device(k[1]) == device]:
+            del cache[k]                       # one geometry per (owner, device) stays resident (a new input size replaces the old set)
         if (name, device, owner) not in cache and torch.cuda.is_current_stream_capturing():
             return self.planes_buffer(rows, ld)  # captured without a warm-up under an owner: the graph's own zero-filled buffer
         return self._split_workspace(name, 2 * (rows + 1) * ld * 2, device)
+
+    def release_cached_planes(self):
+        """Drop every cached activation-plane buffer of this instance (the refinement block keeps ~590 MB per stream at config 4
+        alive between forwards; captured graphs keep their own sets until the graph object dies).  Safe at any time between
+        forwards: the next forward allocates and zeroes a fresh set."""
+        cache = self.__dict__.setdefault('_split_ws', {})
+        for k in [k for k in cache if isinstance(k[0], tuple) and k[0][0] == 'planes']:
+            del cache[k]
 
     def conv_weight_planes_from(self, weight):
         """Uncached: planes of ``weight [cout, cin, kh, kw]`` permuted to ``[cout, kh*kw*cin]`` -> ``(planes, cout, cin, kh, kw)``."""
@@ -603,8 +615,10 @@ class HipOps:
         p_t, p_ld, p_coff = outp
         zt = z if gate == 2 else None
         if addend is not None:
-            if not (addend.dtype == torch.float32 and addend.is_contiguous() and addend.shape[1] == cout):
-                raise ValueError('conv_gru: addend must be contiguous fp32 [rows, cout]')
+            if not (addend.dtype == torch.float32 and addend.is_contiguous() and addend.dim() == 2 and addend.shape[1] == cout
+                    and addend.shape[0] == geom[0] * geom[1] * geom[2]):
+                raise ValueError(f'conv_gru: addend must be contiguous fp32 [b * h * w = {geom[0] * geom[1] * geom[2]}, cout = {cout}], '
+                                 f'got {tuple(addend.shape)}')
             code = self._launch('conv', lambda: self.lib.um_conv2d_gru_add_fwd(
                 gate, _ptr(buf), a_ld, a_coff, buf.numel() // (4 * a_ld), _ptr(wp), _ptr(bias) if bias is not None else None,
                 _ptr(addend), addend.shape[1], _ptr(hidden), _ptr(zt) if zt is not None else None,
