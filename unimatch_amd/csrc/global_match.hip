@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     constexpr int NPIECE = 4 * NS;
     auto k_piece = [&](int t, int i, unsigned char* slot) {
         const int j = i / NS, pl = i % NS;
-        const int row = srow + 4 * j;
+        int row = srow + 4 * j;
+        // <Fp16, 2, 2, false> is the one instantiation at the register limit: keep the compiler from hoisting every piece's lane-constant
+        // address arithmetic out of the tile loop (16 live registers for ~3 VALU per piece; 20 bytes of scratch per lane in round 4)
+        if constexpr (NS == 2 && NV == 2 && !CAUSAL) asm volatile("" : "+v"(row));
         const int key = min(t * TK + row, a.Lk - 1);
         const unsigned off = kbase_bytes + (unsigned)key * (UM_CHANNELS * 2) + ((scp ^ (row & 15)) << 4);
         gsv_dma16(a.kp + pl * a.k_plane_stride, off, slot + pl * PLANE + (16 * wave + 4 * j) * 256);
@@ -173,32 +176,54 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     auto frag = [&](const unsigned char* cur, int ridx /* sub * NS + plane */, int ks) {
         return *reinterpret_cast<const i16x8*>(cur + (ridx / NS) * (32 * 256) + (ridx % NS) * PLANE + (kaddr ^ (ks << 5)));
     };
+    // A fragments of a k-step: the hi planes of the two 32-key sub-tiles are double-buffered (k-step ks + 1 is read while ks
+    // multiplies); the lo planes are consumed by the FIRST two MFMAs of a k-step, so ONE buffer serves them -- the next k-step's lo
+    // fragments are read behind MFMAs 2 and 3, still four MFMAs ahead of their use.  24 registers instead of 32 at NS = 2: what the
+    // <Fp16, 2, 2, false> instantiation was short of (round 4: 256 VGPRs + 20 bytes of scratch per lane).
+    struct Frags {
+        i16x8 hi[2][2];
+        i16x8 lo[2];
+    };
+    auto frag_first = [&](const unsigned char* cur, Frags& fr) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            fr.hi[0][sub] = frag(cur, sub * NS, 0);
+            if (NS == 2) fr.lo[sub] = frag(cur, sub * NS + 1, 0);
+        }
+    };
+    // the read that rides behind MFMA (ks, j)
+    auto frag_next = [&](auto kc, const unsigned char* cur, Frags& fr) {
+        constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF;
+        if constexpr (ks + 1 < 8) {
+            if constexpr (j < 2) fr.hi[(ks + 1) & 1][j] = frag(cur, j * NS, ks + 1);
+            else if constexpr (NS == 2 && j < 4) fr.lo[j - 2] = frag(cur, (j - 2) * NS + 1, ks + 1);
+        }
+    };
     // one MFMA of the tile: index k = ks * MF + j
-    auto mfma_step = [&](auto kc, i16x8 (&fr)[2][2 * NS], f32x16& x0, f32x16& x1) {
+    auto mfma_step = [&](auto kc, Frags& fr, f32x16& x0, f32x16& x1) {
         constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF, bq = ks & 1;
         if constexpr (NS == 2) {
-            // j: 0 lo0*qh  1 lo1*qh  2 hi0*ql  3 hi1*ql  4 hi0*qh  5 hi1*qh      (fr index = sub * 2 + plane)
-            constexpr int sub = j & 1, kpl = (j < 2) ? 1 : 0, qpl = (j == 2 || j == 3) ? 1 : 0;
+            // j: 0 lo0*qh  1 lo1*qh  2 hi0*ql  3 hi1*ql  4 hi0*qh  5 hi1*qh
+            constexpr int sub = j & 1, qpl = (j == 2 || j == 3) ? 1 : 0;
             f32x16& x = sub ? x1 : x0;
-            if constexpr (ks == 0 && j < 2) x = T::mfma(fr[bq][sub * 2 + kpl], qf[qpl][ks], cinit);
-            else x = T::mfma(fr[bq][sub * 2 + kpl], qf[qpl][ks], x);
+            const i16x8 af = (j < 2) ? fr.lo[sub] : fr.hi[bq][sub];
+            if constexpr (ks == 0 && j < 2) x = T::mfma(af, qf[qpl][ks], cinit);
+            else x = T::mfma(af, qf[qpl][ks], x);
         } else {
             constexpr int sub = j;
             f32x16& x = sub ? x1 : x0;
-            if constexpr (ks == 0) x = T::mfma(fr[bq][sub], qf[0][ks], cinit);
-            else x = T::mfma(fr[bq][sub], qf[0][ks], x);
+            if constexpr (ks == 0) x = T::mfma(fr.hi[bq][sub], qf[0][ks], cinit);
+            else x = T::mfma(fr.hi[bq][sub], qf[0][ks], x);
         }
     };
 
     // ---- MFMAs of one tile with nothing interleaved (first tile, and after a slow-path softmax)
     auto mfma_plain = [&](const unsigned char* cur, f32x16& x0, f32x16& x1) {
-        i16x8 fr[2][2 * NS];
-#pragma unroll
-        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        Frags fr;
+        frag_first(cur, fr);
         gsv_static_for(std::make_integer_sequence<int, NM>{}, [&](auto kc) {
-            constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF;
-            if constexpr (j < 2 * NS && ks + 1 < 8) fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
             mfma_step(kc, fr, x0, x1);
+            frag_next(kc, cur, fr);
         });
     };
 
@@ -264,10 +289,9 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     auto fused = [&](auto staging_c, const unsigned char* cur /* K slot of t+1 */, f32x16& x0, f32x16& x1, const f32x16& y0,
                      const f32x16& y1, const float* vt, int tnext2, int inext2) {
         constexpr bool STAGING = decltype(staging_c)::value;
-        i16x8 fr[2][2 * NS];
+        Frags fr;
         f32x4 vv[2][NV];
-#pragma unroll
-        for (int ri = 0; ri < 2 * NS; ++ri) fr[0][ri] = frag(cur, ri, 0);
+        frag_first(cur, fr);
         vload(vt, 0, vv[0]);
         unsigned char* kdst = lds + (inext2 & 1) * KSLOT;
         unsigned char* vdst = lds + VBASE + (inext2 & 3) * VSLOT;
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
             constexpr int K = decltype(kc)::value, ks = K / MF, j = K % MF;
             mfma_step(kc, fr, x0, x1);
             // fillers in this MFMA's shadow
-            if constexpr (j < 2 * NS && ks + 1 < 8) fr[(ks + 1) & 1][j] = frag(cur, j, ks + 1);
+            frag_next(kc, cur, fr);
             constexpr int S0 = K * 32 / NM, S1 = (K + 1) * 32 / NM;
             gsv_static_for(std::make_integer_sequence<int, S1 - S0>{}, [&](auto dc) {
                 constexpr int S = S0 + decltype(dc)::value;
@@ -346,6 +370,11 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     }
 
     // ---- merge the two half-waves' partial softmaxes and write (M = Ms: p = 2^(score + M)) ------------------
+    // (the query index is recomputed here from an opaque copy of the lane id: kept live across the tile loop it was the one register
+    // the <Fp16, 2, 2, false> instantiation spilled)
+    int lane_w = lane;
+    asm volatile("" : "+v"(lane_w));
+    const int qi_w = qwg + wave * 32 + (lane_w & 31);
     const float M = (l == 0.f) ? 3.0e38f : Ms;                     // a lane that met no valid key must not set the common offset
     const float M2 = __shfl_xor(M, 32);
     const float l2 = __shfl_xor(l, 32);
@@ -353,15 +382,15 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     const float f1 = fast_exp2(MM - M), f2 = fast_exp2(MM - M2);
     const float lt = l * f1 + l2 * f2;
     if (a.nsplit > 1) {
-        float* pr = a.partial + (((long)blockIdx.z * gridDim.y + b) * a.Lq + qi) * (2 + NV);
-        if (half == 0 && qi < a.Lq) {
+        float* pr = a.partial + (((long)blockIdx.z * gridDim.y + b) * a.Lq + qi_w) * (2 + NV);
+        if (half == 0 && qi_w < a.Lq) {
             pr[0] = MM;
             pr[1] = lt;
         }
 #pragma unroll
         for (int ch = 0; ch < NV; ++ch) {
             const float a2 = __shfl_xor(acc[ch], 32);
-            if (half == 0 && qi < a.Lq) pr[2 + ch] = acc[ch] * f1 + a2 * f2;
+            if (half == 0 && qi_w < a.Lq) pr[2 + ch] = acc[ch] * f1 + a2 * f2;
         }
         return;
     }
@@ -369,10 +398,10 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
     for (int ch = 0; ch < NV; ++ch) {
         const float a2 = __shfl_xor(acc[ch], 32);
         const float at = acc[ch] * f1 + a2 * f2;
-        if (half == 0 && qi < a.Lq) {
+        if (half == 0 && qi_w < a.Lq) {
             float r = a.alpha * (at / lt);
-            if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi];
-            a.out[((long)b * NV + ch) * a.Lq + qi] = r;
+            if (a.beta != 0.f) r += a.beta * vbase[ch * a.v_chan_stride + qi_w];
+            a.out[((long)b * NV + ch) * a.Lq + qi_w] = r;
         }
     }
 }

@@ -87,10 +87,15 @@ __global__ __launch_bounds__(1024) void instance_norm_reg_kernel(const float* __
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     f32x4 v[EPT];
     float s = 0.f;
+    {   // one 32-bit element offset walked by nthr per step (1024 threads = 128 VGPRs per lane, 96 of them hold the plane: separately
+        // computed 64-bit addresses of the 24 loads spilled 92 bytes per lane)
+        unsigned off = (unsigned)tid;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * nthr;
-        v[e] = i < n4 ? xp[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < EPT; ++e) {
+            v[e] = off < (unsigned)n4 ? xp[off] : f32x4{0.f, 0.f, 0.f, 0.f};
+            off += (unsigned)nthr;
+            asm volatile("" : "+v"(off));
+        }
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
