@@ -107,10 +107,17 @@ def update_block(net, inp, corr, flow, p, pre='refine.'):
     return net, mask, delta
 
 
-def _upsampler(flow2, feature, p, factor, is_depth=False):
+def upsampler_mask(flow2, feature, p):
+    """The upsampler head's convex-combination logits (unimatch.py:56-58, 246-250): cat(flow, feature) -> 3x3 + ReLU -> 1x1."""
     x = torch.cat([flow2, feature], 1)
     x = F.relu(F.conv2d(x, p['upsampler.0.weight'], p['upsampler.0.bias'], padding=1))
-    mask = F.conv2d(x, p['upsampler.2.weight'], p['upsampler.2.bias'])
+    return F.conv2d(x, p['upsampler.2.weight'], p['upsampler.2.bias'])
+
+
+def _upsampler(flow2, feature, p, factor, is_depth=False, taps=None):
+    mask = upsampler_mask(flow2, feature, p)
+    if taps is not None:
+        taps['up_mask'] = mask
     return convex_upsample(flow2, mask, factor, is_depth=is_depth)
 
 
@@ -186,12 +193,12 @@ def unimatch_forward(p, img0, img1, *, num_scales=1, upsample_factor=8, reg_refi
         if not reg_refine:
             if task == 'stereo':
                 pad = torch.cat([-flow, torch.zeros_like(flow)], 1)
-                pred = -_upsampler(pad, f0, p, upsample_factor)[:, :1]
+                pred = -_upsampler(pad, f0, p, upsample_factor, taps=taps)[:, :1]
             elif task == 'depth':
                 pad = torch.cat([flow, torch.zeros_like(flow)], 1)
-                pred = _upsampler(pad, f0, p, upsample_factor, is_depth=True).clamp(min=min_depth, max=max_depth)[:, :1]
+                pred = _upsampler(pad, f0, p, upsample_factor, is_depth=True, taps=taps).clamp(min=min_depth, max=max_depth)[:, :1]
             else:
-                pred = _upsampler(flow, f0, p, upsample_factor)
+                pred = _upsampler(flow, f0, p, upsample_factor, taps=taps)
             continue
         pose_r = pose
         for it in range(num_reg_refine):

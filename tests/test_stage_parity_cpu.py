@@ -50,7 +50,7 @@ def legs():
             os.environ['UM_STAGE_SIZE'] = old_env
 
 
-@pytest.mark.parametrize('cfg', [3, 4, 2])
+@pytest.mark.parametrize('cfg', [3, 4, 2, 5])
 def test_harness_with_the_port_as_backend(legs, cfg):
     assert sp.pf.RUNS[cfg][1:3] == (64, 96)
     rows = sp.run_case(legs, cfg, 'ctor326', 'shift', 1000, nsamples=2, backend=StageOracleOps())

@@ -21,6 +21,11 @@ import stage_parity as sp  # noqa: E402
 pytestmark = pytest.mark.gpu
 SEED = 1000
 CASES = [(cfg, kind) for cfg in (3, 4) for kind in ('shift', 'noise')]
+# round 5: the one-scale configs 1 / 2 / 5 (flow at two sizes, depth) on both weight sets, 2 samples of the config's batch each (the full
+# batches: tools/stage_parity.py --configs 1,2,5, table in profiles/r05_stage_parity_one_scale.txt).  Stages added for them: the upsampler's
+# mask head, the convex combination on the oracle's logits, the depth plane sweep.
+ONE_SCALE_SAMPLES = {1: 1, 2: 2, 5: 2}
+ONE_SCALE_CASES = [(cfg, which) for cfg in (1, 2, 5) for which in ('ctor326', 'conditioned')]
 
 
 @pytest.fixture(scope='module')
@@ -30,6 +35,7 @@ def legs():
     # fp64 GEMM threads beyond the physical cores only slow both down
     pool = sp.StageLegs(workers=8, threads=8, cache=cache if os.path.isdir(cache) else None)
     pool.submit([(cfg, 'ctor326', kind, SEED, i) for cfg, kind in CASES for i in range(sp.pf.RUNS[cfg][3])])
+    pool.submit([(cfg, which, 'shift', SEED, i) for cfg, which in ONE_SCALE_CASES for i in range(ONE_SCALE_SAMPLES[cfg])])
     yield pool
     pool.close()
 
@@ -39,4 +45,23 @@ def test_every_stage_within_twice_the_fp32_port(legs, cfg, kind):
     rows = sp.run_case(legs, cfg, 'ctor326', kind, SEED)
     assert len(rows[0]['gpu_mean']) == sp.pf.RUNS[cfg][3] == 4
     bad = [line for r, line in zip(rows, sp.fmt_rows(rows)) if not sp.gate(r)[1]]
+    assert not bad, '\n' + '\n'.join(bad)
+
+
+@pytest.mark.parametrize('cfg,which', ONE_SCALE_CASES)
+def test_one_scale_configs_stage_by_stage(legs, cfg, which):
+    """Configs 1, 2, 5: every stage within 2 x the fp32 port on both weight sets -- with ONE documented exception: the global
+    correlation softmax / global propagation on CONDITIONED weights (soft softmaxes: every one of the 6144 keys carries weight and a
+    lane's 3072 terms are one fp32 chain; 2.98 x the port at config 2, 2.06 x at config 5, 2.4e-5 px absolute -- located, explained and
+    priced in profiles/r05_stage_parity_one_scale.txt).  Those rows are held to 4 x the port AND to 1e-4 px absolute instead."""
+    rows = sp.run_case(legs, cfg, which, 'shift', SEED, nsamples=ONE_SCALE_SAMPLES[cfg])
+    names = {r['stage'] for r in rows}
+    assert {'encoder', 'xfmr_s0', 'match_s0', 'prop_s0', 'mask_head', 'convex1', 'upsample'} <= names
+    bad = []
+    for r, line in zip(rows, sp.fmt_rows(rows)):
+        worst, ok = sp.gate(r)
+        if not ok and which == 'conditioned' and r['stage'] in ('match_s0', 'prop_s0'):
+            ok = worst <= 4.0 and max(r['gpu_mean']) < 1e-4
+        if not ok:
+            bad.append(line)
     assert not bad, '\n' + '\n'.join(bad)

@@ -17,7 +17,10 @@ Stages (reference file:line):
   k4_it{t}           matching.py:86-123                                     (ori features, flow) -> [B, 81, h, w] cost volume
   refine_it{t}       unimatch.py:295-331 + reg_refine.py:6-119              K4 + update block: flow_{t-1} -> flow_t (last: + mask)
   convex             utils.py:134-152 (unimatch.py:351)                     (flow, mask) -> full-resolution prediction
-  upsample           unimatch.py:246-262                                    (one-scale configs: upsampler head + convex upsampling)
+  mask_head          unimatch.py:56-58, 246-250                             (one-scale configs) (flow, f0) -> convex-combination logits
+  convex1            utils.py:134-152                                       (one-scale configs) (flow, the oracle's logits) -> prediction
+  upsample           unimatch.py:246-262                                    (one-scale configs) both of the above in one piece
+  (depth, config 5: match_s0 = matching.py:203-250 correlation_softmax_depth on the config's intrinsics / pose)
 
 Gate: per stage and per sample, GPU error <= 2 x the fp32 port's error (+ 4 ulp of the stage's mean
 magnitude).  The GPU legs run the config's measured batch in one call (4 samples stacked); the CPU legs run per sample in a
@@ -64,7 +67,7 @@ def stage_names(ck, kw, blocks=True):
             out += [f'k4_it{t}', f'refine_it{t}']
         out.append('convex')
     else:
-        out.append('upsample')
+        out += ['mask_head', 'convex1', 'upsample']
     return out
 
 
@@ -92,7 +95,9 @@ def stage_outputs(name, ck, kw):
         t = int(tail[2:])
         last = t == kw.get('num_reg_refine', 1) - 1
         return [(f'flow_{tail}', 'epe')] + ([('mask_last', 'abs')] if last else [])
-    return [('pred_raw', 'epe')]              # convex / upsample
+    if name == 'mask_head':
+        return [('up_mask', 'abs')]
+    return [('pred_raw', 'epe')]              # convex / convex1 / upsample
 
 
 def _err(got, truth, metric):
@@ -105,6 +110,22 @@ def _err(got, truth, metric):
 
 def _disp(flow, task):
     return torch.cat([-flow, torch.zeros_like(flow)], 1) if task == 'stereo' else flow
+
+
+def _one_scale_pad(flow, task):
+    """(two-channel input of the upsampler, sign of the prediction, depth flag) of the one-scale head (unimatch.py:246-262)."""
+    if task == 'stereo':
+        return torch.cat([-flow, torch.zeros_like(flow)], 1), -1.0, False
+    if task == 'depth':
+        return torch.cat([flow, torch.zeros_like(flow)], 1), 1.0, True
+    return flow, 1.0, False
+
+
+def _one_scale_pred(up, sign, task, kw):
+    if task == 'flow':
+        return up
+    up = sign * up[:, :1]
+    return up.clamp(min=kw.get('min_depth', 1. / 0.5), max=kw.get('max_depth', 1. / 10)) if task == 'depth' else up
 
 
 def _prev_flow(T, t, last_scale):
@@ -146,8 +167,13 @@ def port_stage(name, T, p, ck, kw, img0, img1):
         nb = a.shape[0] // 2
         return {name: hp.transformer_block(a, torch.cat([a[nb:], a[:nb]], 0), tp, i, kw['attn_type'], splits, h, w)}
     if kind == 'match':
-        f0, f1, r = f32(f'f0_{tail}'), f32(f'f1_{tail}'), kw['corr_radius_list'][s]
-        if r == -1:
+        f0, f1, r = f32(f'f0_{tail}'), f32(f'f1_{tail}'), kw.get('corr_radius_list', (-1,) * ns)[s]
+        if task == 'depth':
+            k_cur = kw['intrinsics'].float().clone()
+            k_cur[:, :2] = k_cur[:, :2] / (ck['upsample_factor'] * 2 ** (ns - 1 - s))
+            cand = torch.linspace(kw.get('min_depth', 1. / 0.5), kw.get('max_depth', 1. / 10), kw.get('num_depth_candidates', 64))
+            fp = hp.depth_corr_softmax(f0, f1, k_cur, kw['pose'].float(), cand, kw.get('depth_from_argmax', False), False)
+        elif r == -1:
             fp = hp.global_corr_softmax_flow(f0, f1, False) if task == 'flow' else hp.global_corr_softmax_stereo(f0, f1)
         else:
             fp = hp.local_corr_softmax(f0, f1, r, one_d=(task == 'stereo'))
@@ -174,11 +200,13 @@ def port_stage(name, T, p, ck, kw, img0, img1):
     if kind == 'convex':
         flow = f32(f'flow_it{kw.get("num_reg_refine", 1) - 1}')
         return {'pred_raw': om.convex_upsample(flow, f32('mask_last'), ck['upsample_factor'])}
-    # one-scale configs: upsampler head + convex upsampling (unimatch.py:246-262)
+    # one-scale configs: upsampler head + convex upsampling (unimatch.py:246-262), as a whole and in its two pieces
     flow, f0 = f32(f'flow_prop_s{ls}'), f32(f'f0_s{ls}')
-    if task == 'stereo':
-        return {'pred_raw': -om._upsampler(_disp(flow, task), f0, p, ck['upsample_factor'])[:, :1]}
-    return {'pred_raw': om._upsampler(flow, f0, p, ck['upsample_factor'])}
+    pad, sign, is_depth = _one_scale_pad(flow, task)
+    if name == 'mask_head':
+        return {'up_mask': om.upsampler_mask(pad, f0, p)}
+    mask = f32('up_mask') if name == 'convex1' else om.upsampler_mask(pad, f0, p)
+    return {'pred_raw': _one_scale_pred(om.convex_upsample(pad, mask, ck['upsample_factor'], is_depth=is_depth), sign, task, kw)}
 
 
 # ------------------------------------------------------------------------------------------------ the product, stage by stage
@@ -237,8 +265,20 @@ def gpu_stage(name, G, model, ck, kw, img0, img1):
             return {name: blk.cross_attn_ffn(ops, a, stream, h, w, g_cross, kv_rotate=nb)}
         return {name: blk.cross_attn_ffn(ops, a, torch.cat([stream[nb:], stream[:nb]], 0), h, w, g_cross)}
     if kind == 'match':
-        t0, t1, r = _tok(G[f'f0_{tail}']), _tok(G[f'f1_{tail}']), kw['corr_radius_list'][s]
-        if r == -1:
+        t0, t1, r = _tok(G[f'f0_{tail}']), _tok(G[f'f1_{tail}']), kw.get('corr_radius_list', (-1,) * ns)[s]
+        if task == 'depth':
+            up = float(ck['upsample_factor'] * 2 ** (ns - 1 - s))
+            cand = model._depth_candidates(kw.get('min_depth', 1. / 0.5), kw.get('max_depth', 1. / 10), kw.get('num_depth_candidates', 64),
+                                           t0.device)
+            if hasattr(ops, 'depth_cam') and t0.is_cuda:
+                cam = ops.depth_cam(kw['intrinsics'].to(t0.device), kw['pose'].to(t0.device), up, False)
+            else:
+                kc = kw['intrinsics'].float().clone()
+                kc[:, :2] = kc[:, :2] / up
+                pc = kw['pose'].float()
+                cam = torch.cat([torch.inverse(kc).flatten(1), pc[:, :3, :3].flatten(1), pc[:, :3, 3], kc.flatten(1)], 1).contiguous()
+            fp = ops.depth_corr_softmax(t0, t1, h, w, cam, cand.contiguous(), kw.get('depth_from_argmax', False))
+        elif r == -1:
             fp = ops.global_corr_softmax_flow(t0, t1, h, w, False) if task == 'flow' else ops.global_corr_softmax_stereo(t0, t1, h, w)
         else:
             fp = ops.local_corr_softmax(t0, t1, h, w, r, one_d=(task == 'stereo'))
@@ -275,9 +315,16 @@ def gpu_stage(name, G, model, ck, kw, img0, img1):
         flow = G[f'flow_it{kw.get("num_reg_refine", 1) - 1}']
         return {'pred_raw': ops.convex_upsample(flow, G['mask_last'].contiguous(), ck['upsample_factor'], False)}
     flow, f0 = G[f'flow_prop_s{ls}'], G[f'f0_s{ls}']
-    if task == 'stereo':
-        return {'pred_raw': -model._upsample(_disp(flow, task), f0)[:, :1]}
-    return {'pred_raw': model._upsample(flow, f0)}
+    pad, sign, is_depth = _one_scale_pad(flow, task)
+    pad = pad.contiguous()
+    if name == 'mask_head':
+        mask, nhwc = model._upsample_mask(pad, f0)
+        if nhwc:
+            mask = mask.reshape(nb, h, w, -1).permute(0, 3, 1, 2)
+        return {'up_mask': mask}
+    if name == 'convex1':          # the convex combination alone, on the oracle's logits
+        return {'pred_raw': _one_scale_pred(model._convex(pad, G['up_mask'].contiguous(), is_depth=is_depth), sign, task, kw)}
+    return {'pred_raw': _one_scale_pred(model._upsample(pad, f0, is_depth=is_depth), sign, task, kw)}
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs (worker processes)

@@ -416,10 +416,12 @@ class UniMatch(nn.Module):
             return ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth)
         return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
 
-    def _upsample(self, flow2, f0_map, is_depth=False):
+    def _upsample_mask(self, flow2, f0_map):
+        """The upsampler head (unimatch.py:56-58): convex-combination logits of the full-resolution prediction ->
+        ``(mask, mask_is_nhwc)``; on the GPU the two convolutions run channels-last on the library's kernels."""
         ops = self.ops
         if getattr(ops, 'fused_conv', False) and flow2.is_cuda and self.upsample_factor in (4, 8):
-            # mask head on the library's convolutions, channels-last: cat(flow, feature) -> 3x3 + ReLU -> 1x1 -> NHWC mask
+            # cat(flow, feature) -> 3x3 + ReLU -> 1x1 -> NHWC mask
             b, v, h, w = flow2.shape
             rows = b * h * w
             feat = f0_map.permute(0, 2, 3, 1).reshape(rows, -1)          # a view when f0_map came from tokens
@@ -429,8 +431,13 @@ class UniMatch(nn.Module):
                                         relu=True)
             hp, hc = ops.nhwc_planes_from([hid])
             mask, _, _ = ops.conv2d_nhwc((hp, b, h, w, hc), c2.weight, c2.bias, 1, (0, 0))
-            return ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth, mask_nhwc=True)
-        mask = self.upsampler(torch.cat([flow2, f0_map], 1))
+            return mask, True
+        return self.upsampler(torch.cat([flow2, f0_map], 1)), False
+
+    def _upsample(self, flow2, f0_map, is_depth=False):
+        mask, nhwc = self._upsample_mask(flow2, f0_map)
+        if nhwc:
+            return self.ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth, mask_nhwc=True)
         return self._convex(flow2, mask, is_depth=is_depth)
 
     # ------------------------------------------------------------------ forward
