@@ -28,6 +28,8 @@
  *     pre-scaled by 2^wshift (2^10) so that |w| in [2^-13, 2^5) is covered.  The model's activations on this path are
  *     O(1)..O(10) (LayerNorm / InstanceNorm outputs, features of std 1..4); tests/test_hip_parity_gpu.py sweeps
  *     0.1 .. 100.  There is no per-tensor rescaling: callers with other magnitudes scale by a power of two around the call.
+ *     An element of magnitude >= 65504 on its way into an fp16 operand is NOT silent (round 5): the kernel that converts it raises
+ *     a bit of a sticky, process-wide flag word (um_range_flags below) that says which kind of operand it was.
  */
 #ifndef UNIMATCH_HIP_H
 #define UNIMATCH_HIP_H
@@ -52,6 +54,22 @@ extern "C" {
 
 int um_version(void);
 const char* um_last_error_string(void);
+
+/* Operand-range flags (UM_MODE_EXACT only; bf16 operands have fp32's exponent range).  Kernels on the Transformer / matching path
+ * that turn fp32 values into fp16 hi | lo operands track the largest magnitude they convert and OR a bit into one sticky word in
+ * pinned host memory when it reaches 65504 (the hi plane would be inf and NaN follows downstream; the fp32 reference has no such
+ * limit -- unimatch/transformer.py:58-60).  Reading the word costs no device synchronisation; it reflects every launch that has
+ * FINISHED, so read it after synchronising the stream(s) when the answer must cover the last call.  `reset` != 0 clears it.
+ * The convolution kernels of the CNN encoder / refinement block are not instrumented (instance-normalised / bounded inputs). */
+#define UM_RANGE_PLANES 1u        /* um_*_fwd entry points that split whole fp32 tensors (q, k, v, features): split_planes_kernel */
+#define UM_RANGE_ATTN_TOKENS 2u   /* um_window_attn_qproj_merge_fwd: the source tokens x                                       */
+#define UM_RANGE_ATTN_QUERY 4u    /* ... its projected queries Wq.x                                                           */
+#define UM_RANGE_ATTN_OUTPUT 8u   /* um_window_attn_*merge*_fwd: the attention output fed to the merge Linear                 */
+#define UM_RANGE_FFN_TOKENS 16u   /* um_ffn_*fwd: the concatenated input [x | y]                                              */
+#define UM_RANGE_FFN_HIDDEN 32u   /* ... the hidden activations gelu(W1.[x | y])                                              */
+#define UM_RANGE_KV_TOKENS 64u    /* um_kv4_fwd / the k | v epilogue of um_ffn_kv_fwd: tokens, and the projected keys / values */
+#define UM_RANGE_LINEAR 128u      /* um_linear_fwd: fp32 inputs and plane outputs                                             */
+int um_range_flags(unsigned* flags_out, int reset);
 
 /* =============================================================================================
  * MEASUREMENT ABI (um_timing_*, um_census_*): not part of the reference's operator interface.  It exists so that bench.py and

@@ -1634,3 +1634,59 @@ def test_cost_volume_dilation(ops, dilation):
     want = hp.local_corr_with_flow_dilated(f0.double(), f1.double(), flow.double(), 4, dilation)
     got = ops.local_corr_with_flow(tok(f0).to(DEV), tok(f1).to(DEV), flow.to(DEV), h, w, 4, dilation=dilation)
     assert got.shape == want.shape and err(got, want)[1] < 3e-6 * max(1.0, want.abs().max().item())
+
+
+def test_operand_range_overflow_is_loud():
+    """exact mode has fp16's exponent range.  An activation >= 65504 on its way into an fp16 hi | lo operand
+    raises a bit of the library's sticky flag word (um_range_flags) that names the operand; UniMatch.forward / check_operand_range
+    turn it into an exception instead of NaN predictions.  Legal magnitudes leave the word at zero; bf16 (fast mode) has no such
+    cliff and never raises it."""
+    from unimatch_amd import _abi
+    ops, fast = HipOps('exact'), HipOps('fast')
+    _abi.range_flags(reset=True)
+    c, m = 128, 4 * 16 * 24
+    x = rnd(970, m, c, scale=1.5).to(DEV)
+    y = rnd(971, m, c, scale=1.5).to(DEV)
+    w1 = (rnd(972, 8 * c, 2 * c, scale=0.06)).to(DEV)
+    w2 = (rnd(973, c, 8 * c, scale=0.03)).to(DEV)
+    wq, wk, wv, wm = (rnd(974 + i, c, c, scale=0.09).to(DEV) for i in range(4))
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    kv, _, n2 = ops.linear_planes(x, (wk, wv))
+    attn = lambda o, t: o.window_attention_qproj_merge(t, wq, (kv, m, n2, 0), (kv, m, n2, c), 4, 16, 24, 8, 12, 0, 0, 0, wm, norm, t)
+    attn(ops, x)
+    ops.ffn_ln(x, y, w1, w2, norm)
+    torch.cuda.synchronize()
+    assert _abi.range_flags() == 0                                     # the model's magnitudes: nothing raised
+    big = x.clone()
+    big[5, 7] = 1.0e5                                                   # one activation beyond fp16
+    out = attn(ops, big)
+    torch.cuda.synchronize()
+    flags = _abi.range_flags()
+    assert flags & 2 and not torch.isfinite(out).all(), flags          # UM_RANGE_ATTN_TOKENS, and the result really is not finite
+    with pytest.raises(_abi.OperandRangeError, match='attention source tokens'):
+        _abi.check_operand_range()
+    assert _abi.range_flags() == 0                                     # reading through check_* clears the word
+    ops.ffn_ln(big, y, w1, w2, norm)
+    ops.linear_planes(big, (wk, wv))
+    torch.cuda.synchronize()
+    flags = _abi.range_flags(reset=True)
+    assert flags & 16 and flags & 128, flags                           # UM_RANGE_FFN_TOKENS, UM_RANGE_LINEAR
+    ops.ffn_ln(x * 3000.0, y * 3000.0, w1 * 8.0, w2, norm)              # inputs legal (|x| < 3e4), the hidden activations are not
+    torch.cuda.synchronize()
+    flags = _abi.range_flags(reset=True)
+    assert flags & 32 and not flags & 16, flags                        # UM_RANGE_FFN_HIDDEN only
+    kvf, _, _ = fast.linear_planes(big, (wk, wv))                       # bf16 operands carry fp32's range: no flag, finite results
+    outf = fast.window_attention_qproj_merge(big, wq, (kvf, m, n2, 0), (kvf, m, n2, c), 4, 16, 24, 8, 12, 0, 0, 0, wm, norm, big)
+    torch.cuda.synchronize()
+    assert _abi.range_flags() == 0 and torch.isfinite(outf).all()
+    # the drop-in module: the NEXT forward after an overflow refuses loudly (no synchronisation on the hot path), and
+    # check_operand_range() covers the call that has just been made
+    model, i0, i1, fk = _graph_case('gmflow_s1', 64, 96)
+    model(i0, i1, **fk)
+    model.check_operand_range()                                        # clean
+    attn(ops, big)
+    torch.cuda.synchronize()
+    with pytest.raises(_abi.OperandRangeError, match='earlier forward'):
+        model(i0, i1, **fk)
+    model(i0, i1, **fk)                                                # the flags were cleared by the report
+    model.check_operand_range()

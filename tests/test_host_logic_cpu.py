@@ -182,6 +182,14 @@ def test_library_exports_every_declared_symbol():
     assert 'um_debug_' not in exported, [ln for ln in exported.splitlines() if 'um_debug_' in ln]
 
 
+def test_operand_range_flag_word_without_gpu():
+    """um_range_flags: argument check, and a readable (zero) word on a host without a GPU."""
+    lib = _abi.load()
+    assert lib.um_range_flags(None, 0) == -1
+    assert _abi.range_flags() == 0 and _abi.range_flags(reset=True) == 0
+    _abi.check_operand_range()                                          # nothing raised: no exception
+
+
 def test_abi_argument_errors_without_gpu():
     """Argument validation happens before any launch, so it can be exercised on a GPU-less host."""
     lib = _abi.load()

@@ -22,6 +22,7 @@ _c_int, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 SIGNATURES = {
     'um_version': (_c_int, []),
     'um_last_error_string': (ctypes.c_char_p, []),
+    'um_range_flags': (_c_int, [ctypes.POINTER(ctypes.c_uint), _c_int]),
     'um_timing_enable': (_c_int, [_c_int]),
     'um_timing_collect': (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
     'um_window_attn_workspace_bytes': (_c_size_t, [_c_int] * 4),
@@ -112,6 +113,11 @@ DIAG_SIGNATURES = {
     'um_debug_mfma_ticks': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
+# um_range_flags bits (UM_RANGE_* of the header) -> what overflowed fp16's range on its way into an exact-mode operand
+RANGE_ROLES = {1: 'a tensor converted to operand planes (q / k / v / features)', 2: 'attention source tokens', 4: 'projected queries',
+               8: 'attention output (input of the merge Linear)', 16: 'FFN input [x | y]', 32: 'FFN hidden activations',
+               64: 'tokens / projected keys and values of the k | v projection', 128: 'inputs / plane outputs of a Linear'}
+
 _lib = None
 
 
@@ -171,3 +177,25 @@ def check(code, what):
     if code < 0:
         raise ValueError(f'{what}: {msg} (code {code})')
     raise RuntimeError(f'{what}: HIP error {code}')
+
+
+class OperandRangeError(FloatingPointError):
+    """An activation reached fp16's largest finite value (65504) on its way into an exact-mode MFMA operand."""
+
+
+def range_flags(reset=False):
+    """The sticky operand-range word (``um_range_flags``): a bit per kind of operand that overflowed in a FINISHED launch."""
+    out = ctypes.c_uint(0)
+    check(load().um_range_flags(ctypes.byref(out), 1 if reset else 0), 'um_range_flags')
+    return out.value
+
+
+def check_operand_range(where=''):
+    """Raise :class:`OperandRangeError` naming the operands that overflowed since the last check (and clear the flags)."""
+    flags = range_flags(reset=True)
+    if flags:
+        roles = '; '.join(v for k, v in RANGE_ROLES.items() if flags & k)
+        raise OperandRangeError(
+            f'{where}exact mode splits fp32 values into fp16 hi | lo operands, and an element of magnitude >= 65504 reached: {roles} '
+            '(the hi plane is inf there and NaN follows downstream; the fp32 reference has no such limit).  Scale the inputs / '
+            "weights by a power of two, or run precision='fast' (bf16 operands: fp32's exponent range).")

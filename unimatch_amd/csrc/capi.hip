@@ -113,3 +113,47 @@ extern "C" long um_census_count(int variant) {
     if (variant < 0 || variant >= UM_V_COUNT) return -1;
     return g_census[variant].load(std::memory_order_relaxed);
 }
+
+// ---- operand-range flag word (include/unimatch_hip.h, um_range_flags): one unsigned in pinned, mapped host memory; kernels receive
+// its device address in their argument structs and OR a role bit into it (system-scope atomic) in the rare overflow case.
+namespace {
+std::once_flag g_range_once;
+unsigned* g_range_host = nullptr;
+void range_alloc() {
+    unsigned* p = nullptr;
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+        *p = 0u;
+        g_range_host = p;
+    }
+    (void)hipGetLastError();
+}
+}  // namespace
+
+// device address of the flag word for the CURRENT device (nullptr when pinned memory cannot be had: the kernels then skip the note)
+unsigned* um_range_flag_dev() {
+    std::call_once(g_range_once, range_alloc);
+    if (!g_range_host) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, g_range_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (unsigned*)d;
+}
+
+extern "C" int um_range_flags(unsigned* flags_out, int reset) {
+    if (!flags_out) {
+        um_set_error("um_range_flags: null output");
+        return UM_ERR_BAD_ARG;
+    }
+    std::call_once(g_range_once, range_alloc);
+    if (!g_range_host) {
+        *flags_out = 0u;
+        return 0;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    volatile unsigned* v = g_range_host;
+    *flags_out = *v;
+    if (reset) *v = 0u;
+    return 0;
+}

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/unimatch_hip.h"
 
 // A/B switches for same-box timing runs exist ONLY in diagnostic builds (-DUM_DEBUG_SWITCHES, `python -m unimatch_amd.build
 // --variant NAME -DUM_DEBUG_SWITCHES ...` -> unimatch_amd/_variants/libNAME.so, loaded through UM_LIB): the shipped library never
@@ -106,6 +107,19 @@ struct Bf16 {
                                                        __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+
+// ---- operand-range note (um_range_flags, include/unimatch_hip.h): `mx` = the largest |value| this lane turned into an fp16
+// operand; at 65504 the hi plane is inf.  One compare per lane at the end of a section; the atomic only ever runs on overflow.
+template <class T> struct UmRange;
+template <> struct UmRange<Fp16> { static constexpr float limit = 65504.0f; };
+template <> struct UmRange<Bf16> { static constexpr float limit = 3.0e38f; };
+template <class T>
+__device__ __forceinline__ void um_range_note(unsigned* flag, float mx, unsigned bit) {
+#ifndef UM_NO_RANGE_NOTE          // (diagnostic builds: what the tracking costs -- the maxima are dead code without the note)
+    if (flag != nullptr && !(mx < UmRange<T>::limit)) __hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+unsigned* um_range_flag_dev();          // capi.hip: device address of the sticky flag word (nullptr: unavailable)
 
 // -1.0f in an SGPR whose value the compiler cannot see (see Fp16::lo2)
 __device__ __forceinline__ float um_opaque_neg1() {

@@ -50,6 +50,7 @@ struct Kv4Args {
     long out_plane_stride;       // 4 * M * 128
     int M;
     float out_scale;             // 2^-wshift
+    unsigned* range_flag;        // um_range_flags: sticky operand-range word (device address; nullptr: none)
 };
 
 struct FfnArgs {
@@ -71,6 +72,7 @@ struct FfnArgs {
     unsigned* hs_flag;            // [tiles] arrival counters, zero between launches
     // KV4 variant: the NEXT block's key / value projections of the tile this workgroup has just finished (kv4_project)
     Kv4Args kv;
+    unsigned* range_flag;         // um_range_flags (as Kv4Args)
 };
 
 // the same with the LDS destination as an ADDRESS (an SGPR value): a flat pointer into the LDS array costs an address-space cast
@@ -264,6 +266,7 @@ __device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* 
             }
     };
     if (!CHUNK0_ISSUED) dma(0, 0);
+    float kmx = 0.f;                                               // largest projected key / value element (um_range_flags)
 #pragma unroll 1
     for (int c = 0; c < 8; ++c) {
         const int slot = c & 1;
@@ -311,6 +314,7 @@ __device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* 
         for (int g = 0; g < 4; ++g) {
             const float v0 = acc[4 * g] * k.out_scale, v1 = acc[4 * g + 1] * k.out_scale, v2 = acc[4 * g + 2] * k.out_scale,
                         v3 = acc[4 * g + 3] * k.out_scale;
+            kmx = fmaxf(fmaxf(kmx, fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1))), fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3)));
             const unsigned h0 = T::pack2(v0, v1), h1 = T::pack2(v2, v3);
             *reinterpret_cast<u32x2*>(dp + ((g ^ sw) << 4)) = u32x2{h0, h1};
             if (NS == 2) {
@@ -320,6 +324,7 @@ __device__ __forceinline__ void kv4_project(unsigned char* ring, unsigned char* 
         }
     }
     store_chunk(7);
+    um_range_note<T>(k.range_flag, kmx, UM_RANGE_KV_TOKENS);
 }
 
 template <typename T, int NS>
@@ -335,10 +340,13 @@ __global__ __launch_bounds__(512, 2) void kv4_kernel(Kv4Args k) {
     i16x8 yf[NS][8];
     {
         const float* src = k.x + (long)min(tok, k.M - 1) * 128 + 8 * half;
+        float xmx = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xmx = fmaxf(xmx, fmaxf(__builtin_fabsf(v0[j]), __builtin_fabsf(v1[j])));
             const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
             yf[0][ks] = __builtin_bit_cast(i16x8, h);
             if (NS == 2) {
@@ -347,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void kv4_kernel(Kv4Args k) {
                 yf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
             }
         }
+        um_range_note<T>(k.range_flag, xmx, UM_RANGE_KV_TOKENS);
     }
     const int arow = tl ^ (16 * role);
     int aoff[8];
@@ -450,10 +459,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     i16x8 xf[NS][8];
     {
         const float* src = (role ? a.y : a.x) + (long)min(tok, a.M - 1) * 128 + 8 * half;
+        float xmx = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f32x4 v0 = UM_FFN_LD(reinterpret_cast<const f32x4*>(src + 16 * ks));
             const f32x4 v1 = UM_FFN_LD(reinterpret_cast<const f32x4*>(src + 16 * ks + 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xmx = fmaxf(xmx, fmaxf(__builtin_fabsf(v0[j]), __builtin_fabsf(v1[j])));
             const u32x4 h = {T::pack2(v0[0], v0[1]), T::pack2(v0[2], v0[3]), T::pack2(v1[0], v1[1]), T::pack2(v1[2], v1[3])};
             xf[0][ks] = __builtin_bit_cast(i16x8, h);
             if (NS == 2) {
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 xf[NS - 1][ks] = __builtin_bit_cast(i16x8, l);
             }
         }
+        um_range_note<T>(a.range_flag, xmx, UM_RANGE_FFN_TOKENS);
     }
 
     f32x16 o[4];
@@ -543,11 +556,15 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
     struct Frag {
         unsigned wh[4], wl[4];
     };
+    float hmx = 0.f;                // largest hidden activation turned into an operand (um_range_flags)
     auto frag_stage = [&](Frag& f, const Gelu2* g, i16x8* pf, int stage) {
         switch (stage) {
         case 0:
 #pragma unroll
-            for (int q = 0; q < 4; ++q) f.wh[q] = T::pack2(g[q].x[0], g[q].x[1]);
+            for (int q = 0; q < 4; ++q) {
+                hmx = fmaxf(hmx, fmaxf(__builtin_fabsf(g[q].x[0]), __builtin_fabsf(g[q].x[1])));
+                f.wh[q] = T::pack2(g[q].x[0], g[q].x[1]);
+            }
             break;
         case 1:                                  // lo plane: 2 x (v_fma_mixlo_f16 + v_fma_mixhi_f16) per stage (Fp16::lo2)
             if (NS == 2 && !UM_FFN_H1) {
@@ -954,6 +971,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
 #ifdef UM_FFN_TRACE
     if (tracing) trace_buf[24 * 8 + 1] = __builtin_amdgcn_s_memtime();
 #endif
+    um_range_note<T>(a.range_flag, hmx, UM_RANGE_FFN_HIDDEN);
     // ---- epilogue: add the partner's partial O, LayerNorm over the 128 outputs, residual ------------------------------
     __syncthreads();                                               // every ring slot and exchange buffer is dead
     static_assert(!(KV4 && HSPLIT), "the k | v epilogue runs on whole tiles only");
@@ -1237,6 +1255,7 @@ static int ffn_impl(const float* x, const float* y, const void* w1_planes, const
     a.hs_part = nullptr;
     a.hs_flag = nullptr;
     a.kv = Kv4Args{};
+    a.range_flag = a.kv.range_flag = (mode == 0) ? um_range_flag_dev() : nullptr;
     if (workspace) {
         const int split = ffn_hidden_split(m, hidden);
         if (split > 1 && workspace_bytes >= ffn_hs_bytes(m, split)) {
@@ -1281,6 +1300,7 @@ extern "C" int um_kv4_fwd(const float* x, const void* wc_planes, int m, int wshi
     k.out_plane_stride = 4L * m * 128;
     k.M = m;
     k.out_scale = ldexpf(1.f, -wshift);
+    k.range_flag = (mode == 0) ? um_range_flag_dev() : nullptr;
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipSuccess;
     ScopedKernelTimer timer(UM_K_LINEAR, stream);

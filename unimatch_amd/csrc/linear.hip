@@ -44,6 +44,7 @@ struct LinArgs {
     float eps;
     const float* bias;            // optional [N]: C = A.W^T * out_scale + bias * bias_scale  (nn.Linear with bias)
     float bias_scale;
+    unsigned* range_flag;         // um_range_flags: sticky operand-range word (device address; nullptr: none)
 };
 
 __device__ __forceinline__ void lin_dma16(const void* base, unsigned byte_off, const unsigned char* lds_dst) {
@@ -112,10 +113,13 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
             areg[i] = *reinterpret_cast<const f32x4*>(src + (long)grow * ld + kk + 4 * (tid & 7));
         }
     };
+    float rmx = 0.f;                 // largest magnitude turned into an fp16 operand (fp32 inputs, plane outputs; um_range_flags)
     auto store_a = [&](unsigned char* dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 32 * i + (tid >> 3), f4 = tid & 7;
+            rmx = fmaxf(fmaxf(rmx, fmaxf(__builtin_fabsf(areg[i][0]), __builtin_fabsf(areg[i][1]))),
+                        fmaxf(__builtin_fabsf(areg[i][2]), __builtin_fabsf(areg[i][3])));
             const unsigned h0 = T::pack2(areg[i][0], areg[i][1]), h1 = T::pack2(areg[i][2], areg[i][3]);
             unsigned char* p = dst + r * 64 + (((f4 >> 1) ^ ((r >> 2) & 3)) << 4) + (f4 & 1) * 8;
             *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
                     if (EPI == EPI_GELU_PLANES) v[i] = gelu_erf(v[i]);
                 }
                 unsigned char* p = stg + tl * 256 + (((4 * nt + g) ^ (tl & 15)) << 4) + 8 * half;
+                rmx = fmaxf(fmaxf(rmx, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
                 const unsigned h0 = T::pack2(v[0], v[1]), h1 = T::pack2(v[2], v[3]);
                 *reinterpret_cast<u32x2*>(p) = u32x2{h0, h1};
                 if (NS == 2) {
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
                     *reinterpret_cast<u32x2*>(p + 32768) = u32x2{l0, l1};
                 }
             }
+        um_range_note<T>(a.range_flag, rmx, UM_RANGE_LINEAR);
         __builtin_amdgcn_wave_barrier();                          // same wave: LDS executes its accesses in order
         const int row0 = m0 + 32 * wave;
 #pragma unroll
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinArgs a) {
                     *reinterpret_cast<u32x4*>(a.outp + pl * a.out_plane_stride + (long)(row0 + r) * a.N + n0 + 8 * cch) = d;
             }
     } else {
+        um_range_note<T>(a.range_flag, rmx, UM_RANGE_LINEAR);       // (fp32 inputs of this launch)
         // LayerNorm over the N = 128 features of the token (two-pass in registers), optional residual
         float s1 = 0.f;
 #pragma unroll
@@ -368,6 +375,7 @@ extern "C" int um_linear_fwd(const float* a0, const float* a1, const void* a_pla
     a.eps = eps;
     a.bias = nullptr;
     a.bias_scale = 0.f;
+    a.range_flag = (mode == 0) ? um_range_flag_dev() : nullptr;
     hipError_t e;
     if (a_planes) {
         if (epilogue == EPI_LN) e = launch_linear<A_PLANES, EPI_LN>(a, mode, stream);
@@ -427,6 +435,7 @@ extern "C" int um_linear_bias_fwd(const float* a0, const void* a_planes, const v
     a.eps = 0.f;
     a.bias = bias;
     a.bias_scale = bias_mul;
+    a.range_flag = (mode == 0) ? um_range_flag_dev() : nullptr;
     hipError_t e;
     if (a_planes) e = out_planes ? launch_linear<A_PLANES, EPI_PLANES>(a, mode, stream) : launch_linear<A_PLANES, EPI_F32>(a, mode, stream);
     else e = out_planes ? launch_linear<A_F32, EPI_PLANES>(a, mode, stream) : launch_linear<A_F32, EPI_F32>(a, mode, stream);

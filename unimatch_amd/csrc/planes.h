@@ -9,9 +9,10 @@
 template <class T, int NS>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src,
                                                            unsigned short* __restrict__ dst,
-                                                           long n8, float scale, long plane_stride) {
+                                                           long n8, float scale, long plane_stride, unsigned* range_flag) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long step = (long)gridDim.x * blockDim.x;
+    float mx = 0.f;
     for (; i < n8; i += step) {
         const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + 2 * i;
         f32x4 a = s4[0], b = s4[1];
@@ -19,7 +20,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         float y[8];
         u32x4 hi;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = x[j] * scale;
+        for (int j = 0; j < 8; ++j) {
+            y[j] = x[j] * scale;
+            mx = fmaxf(mx, __builtin_fabsf(y[j]));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) hi[j] = T::pack2(y[2 * j], y[2 * j + 1]);
         *reinterpret_cast<u32x4*>(dst + 8 * i) = hi;
@@ -33,6 +37,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
             *reinterpret_cast<u32x4*>(dst + plane_stride + 8 * i) = lo;
         }
     }
+    um_range_note<T>(range_flag, mx, UM_RANGE_PLANES);
 }
 
 // n_elems fp32 values (a multiple of 8) -> planes at dst, plane stride n_elems.  Returns hipError_t of the launch.
@@ -55,10 +60,10 @@ static inline hipError_t launch_split_elems(const float* src, unsigned short* ds
     ScopedKernelTimer timer(UM_K_SPLIT_PLANES, stream);
     if (mode == 0)
         hipLaunchKernelGGL((split_planes_kernel<Fp16, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n8,
-                           scale, plane_stride);
+                           scale, plane_stride, um_range_flag_dev());
     else
         hipLaunchKernelGGL((split_planes_kernel<Bf16, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n8,
-                           scale, plane_stride);
+                           scale, plane_stride, (unsigned*)nullptr);
     return hipGetLastError();
 }
 

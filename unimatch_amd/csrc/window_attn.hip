@@ -88,6 +88,7 @@ struct WattnArgs {
     int split;
     float* ks_part;              // [split tiles][split][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of every part
     unsigned* ks_flag;           // [split tiles] arrival counters, zero between launches
+    unsigned* range_flag;        // um_range_flags: sticky operand-range word (device address; nullptr: none)
 };
 
 // window-local token -> global token index and its mask class.
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // hi | lo in registers exactly as split_planes_kernel would; the accumulators turn into the Q^T operand
         // fragments the way P^T does.
         i16x8 xf[NS][8];
+        float rmx = 0.f;                 // largest magnitude turned into an fp16 operand (um_range_flags)
         {
             const float* xb = a.x + (sbase + tokq) * UM_CHANNELS + 8 * half;
 #pragma unroll
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const float y[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
                 u32x4 hi, lo;
 #pragma unroll
+                for (int j = 0; j < 8; ++j) rmx = fmaxf(rmx, __builtin_fabsf(y[j]));
+#pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     hi[j] = T::pack2(y[2 * j], y[2 * j + 1]);
                     if (NS == 2) lo[j] = T::lo2(y[2 * j], y[2 * j + 1], hi[j], neg1);
@@ -256,6 +260,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 if (NS == 2) xf[NS - 1][ks] = __builtin_bit_cast(i16x8, lo);
             }
         }
+        um_range_note<T>(a.range_flag, rmx, UM_RANGE_ATTN_TOKENS);
+        rmx = 0.f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float p0 = acc[8 * kk + 2 * j] * a.wm_scale, p1 = acc[8 * kk + 2 * j + 1] * a.wm_scale;
+                    rmx = fmaxf(rmx, fmaxf(__builtin_fabsf(p0), __builtin_fabsf(p1)));
                     wh[j] = T::pack2(p0, p1);
                     if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
                 }
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 }
             }
         }
+        um_range_note<T>(a.range_flag, rmx, UM_RANGE_ATTN_QUERY);
         __syncthreads();        // every wave is done with Wq: the ring may take tile 0
     }
 
@@ -740,6 +748,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     i16x8 of[NS][8];
+    float omx = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         const int dt = ks >> 1, r0 = 8 * (ks & 1);
@@ -747,6 +756,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float p0 = o[dt][r0 + 2 * j] * inv, p1 = o[dt][r0 + 2 * j + 1] * inv;
+            omx = fmaxf(omx, fmaxf(__builtin_fabsf(p0), __builtin_fabsf(p1)));
             wh[j] = T::pack2(p0, p1);
             if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
         }
@@ -763,6 +773,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             of[NS - 1][ks] = __builtin_bit_cast(i16x8, f);
         }
     }
+    um_range_note<T>(a.range_flag, omx, UM_RANGE_ATTN_OUTPUT);
     f32x16 yv[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
@@ -1690,6 +1701,7 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.split = 1;
     a.ks_part = nullptr;
     a.ks_flag = nullptr;
+    a.range_flag = (mode == 0) ? um_range_flag_dev() : nullptr;
     a.wm = wm;
     a.wm_plane_stride = (long)UM_CHANNELS * UM_CHANNELS;
     a.gamma = gamma;

@@ -416,6 +416,16 @@ class UniMatch(nn.Module):
             return ops.convex_upsample(flow2, mask, self.upsample_factor, is_depth)
         return convex_upsample(flow2, mask, self.upsample_factor, is_depth=is_depth)
 
+    check_range = True       # read the operand-range flags at the start of every exact-mode forward (no synchronisation)
+
+    def check_operand_range(self, sync=True):
+        """Raise ``_abi.OperandRangeError`` if any exact-mode kernel met an activation outside fp16's range since the last check
+        (``sync``: wait for the device first, so that the forward that has just been enqueued is covered)."""
+        from . import _abi
+        if sync and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        _abi.check_operand_range()
+
     def _upsample_mask(self, flow2, f0_map):
         """The upsampler head (unimatch.py:56-58): convex-combination logits of the full-resolution prediction ->
         ``(mask, mask_is_nhwc)``; on the GPU the two convolutions run channels-last on the library's kernels."""
@@ -460,6 +470,13 @@ class UniMatch(nn.Module):
             self._check_weight_print()
         attn_type = attn_type if attn_type is not None else ''
         dev = img0.device
+        # Operand range of exact mode (include/unimatch_hip.h): the kernels raise a sticky flag in pinned host memory when an
+        # activation >= 65504 is turned into an fp16 operand.  Reading it costs no synchronisation, so it is read HERE, at the start
+        # of every forward: an overflow of an earlier (finished) forward is reported loudly instead of living on as NaN predictions;
+        # `check_operand_range()` synchronises first and covers the call that has just been made.
+        if img0.is_cuda and self.check_range and getattr(ops, 'mode', 1) == 0:
+            from . import _abi
+            _abi.check_operand_range('an earlier forward of this process: ')
 
         # every launch of the library goes to torch's CURRENT stream and scratch buffers are allocated on the current device:
         # make the inputs' device current for the whole forward (a model on cuda:1 called while cuda:0 is current)
