@@ -413,7 +413,10 @@ int um_local_corr_with_flow_planes(const float* f0, const float* f1, const float
  *   um_local_corr_with_flow_feat_supported(...)         1 for radius 4 on maps of whole 8 x 4 tiles
  *   um_local_corr_with_flow_feat(...)                   exactly one of `cost` ([B, 81, h, w] fp32) and `planes_out` (as
  *                                                       um_local_corr_with_flow_planes) non-null; flags bit 0 = every tile on
- *                                                       the pixel-at-a-time path (A/B timing). */
+ *                                                       the pixel-at-a-time path, bit 1 = natural 8 x 4 tiles only (A/B timing).
+ *   Where more than a quarter of a launch's natural tiles have incoherent flow (no common 32 x 24 window) the pixels are grouped by
+ *   the 16 x 8 cell of f1 they sample (counting sort on the device, scratch inside `feat_planes`) and the groups run on the matrix
+ *   cores: the choice is a function of the call's flow alone and the result is bitwise reproducible (profiles/r05_k4_target_order.txt). */
 size_t um_local_corr_feat_planes_bytes(int batch, int h, int w, int channels);
 int um_local_corr_feat_planes(const float* f0, const float* f1, void* feat_planes, int batch, int h, int w, int channels,
                               void* stream);

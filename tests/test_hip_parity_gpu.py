@@ -1304,6 +1304,21 @@ def test_cost_volume_dispatch_is_a_pure_function_of_the_call():
     census = _abi.census(lib)
     lib.um_census_enable(0)
     assert census['k4_mfma'] == 10 and census['k4_valu'] == 0
+    # round 5: incoherent flow is served TARGET-ORDERED (pixels grouped by the cell of f1 they sample: every group shares one window
+    # and runs on the matrix cores).  Switched off (flags bit 1: natural tiles, pixel path) the same call must agree to rounding --
+    # and with flows that leave the map entirely the groups that sample nothing must write exact zeros either way.
+    o.k4_flags = 2
+    try:
+        natural = o.local_corr_with_flow(t0, t1, noisy, h, w, 4)
+    finally:
+        o.k4_flags = 0
+    scale = max(1.0, want[id(noisy)].abs().max().item())
+    assert err(natural, want[id(noisy)])[1] < 3e-6 * scale and err(natural, first[id(noisy)])[0] < 3e-6 * scale
+    away = noisy.clone()
+    away[:, 0, :, : w // 2] += 500.0                                           # left half samples far right of the image
+    got_away = o.local_corr_with_flow(t0, t1, away, h, w, 4)
+    assert torch.equal(got_away[:, :, :, : w // 2], torch.zeros_like(got_away[:, :, :, : w // 2]))
+    assert torch.equal(got_away[:, :, :, w // 2:], first[id(noisy)][:, :, :, w // 2:])      # the other pixels: bitwise as before
     # a geometry the matrix-core kernel does not serve (width not a multiple of 8) always takes the VALU kernel
     lib.um_census_enable(1)
     f0b, f1b = rnd(153, 1, C, 12, 20), rnd(154, 1, C, 12, 20)

@@ -19,6 +19,18 @@
 //   * tiles whose window does not fit 32 x 24 (motion boundaries; everything at random init) take the pixel-at-a-time VALU
 //     path inside the same kernel -- the dot products of that path are the VALU kernel's.
 // The feature planes are split once per scale (um_local_corr_feat_planes) and serve every refinement iteration.
+//
+// Target-ordered tiles (round 5).  Where the flow is INCOHERENT (random-init weights; motion boundaries) a natural 8 x 4 tile
+// has no common window: round 4 measured the pixel path at 20 x its compulsory bytes (2.1 GB per launch at 4 x 128 x 192) with
+// the waves parked 69 % of the time.  But pixels whose TARGETS lie in one 16 x 8 cell of f1 always share a 26 x 18 window,
+// wherever they sit in f0.  So a launch first takes a census of its natural tiles (k4s_census_kernel); if more than a quarter
+// of them are incoherent the pixels are counting-sorted by (image, target cell) -- histogram in the census, prefix sum by
+// the census' last block, scatter of pixel ids into per-cell groups padded to whole 32-pixel tiles (k4s_scatter_kernel) -- and
+// k4m_kernel walks those groups: lane = any pixel of the group, everything downstream (B operand, scatter addresses, blend
+// weights, output row) was per lane already.  Pixels whose whole neighbourhood misses the image go to one group that writes
+// zeros.  Properties kept: the decision is a pure function of the call's flow (no state, no host read-back); a pixel's 100 dot
+// products do not depend on which other pixels share its tile (one MFMA column per pixel), and every sorted tile is coherent by
+// construction, so the result does not depend on the order the scatter's atomics happen to produce: bitwise reproducible.
 #include "common.h"
 #include "planes.h"
 
@@ -31,6 +43,10 @@ extern void um_set_error(const char* fmt, ...);
 #define K4M_TW 8
 #define K4M_TH 4
 #define K4M_MAXROWS 24
+#ifndef K4S_CW
+#define K4S_CW 16                // target cell: 16 x 8 positions of f1  ->  window (16 + 10) x (8 + 10) <= 32 x 24
+#define K4S_CH 8
+#endif
 
 struct K4mArgs {
     const float* f0;             // [B][L][128] fp32 tokens (VALU path)
@@ -49,7 +65,146 @@ struct K4mArgs {
     // 9 x 9 neighbourhood: every tile is coherent), softmax over the 81 taps, expected offset -> flow_out [B][2][h][w]
     float* flow_out;
     unsigned* stats;             // optional: [0] += tiles on the product path, [1] += tiles on the pixel path (adaptive dispatch)
+    // target-ordered mode (see the header): scratch of the launch, filled by the k4s_* kernels that run in front of it
+    const int* perm;             // [ncell groups padded to 32] pixel ids (b * L + p), -1 = empty slot
+    const unsigned* ctl;         // [0] = 1: walk the sorted groups, [1] = number of sorted tiles
 };
+
+// ---- scratch layout of the target-ordered mode (inside the feature-plane workspace, behind the planes)
+struct K4sLayout {
+    int cx, cy, ncell;           // cells per image: (cx x cy) inside + 1 "nothing to sample" cell
+    long rows;
+    size_t off_ctl, off_hist, off_base, off_cursor, off_cell, off_perm, bytes;
+};
+static inline K4sLayout k4s_layout(int batch, int h, int w) {
+    K4sLayout l;
+    l.cx = (w + K4S_CW - 1) / K4S_CW + 2;        // targets up to a window outside the image still touch it
+    l.cy = (h + K4S_CH - 1) / K4S_CH + 2;
+    l.ncell = l.cx * l.cy + 1;
+    l.rows = (long)batch * h * w;
+    const size_t nb = (size_t)batch * l.ncell;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+    l.off_ctl = take(64);
+    l.off_hist = take(nb * 4);
+    l.off_base = take(nb * 4);
+    l.off_cursor = take(nb * 4);
+    l.off_cell = take((size_t)l.rows * 4);
+    l.off_perm = take(((size_t)l.rows + 32 * nb) * 4);
+    l.bytes = o;
+    return l;
+}
+
+// cell of a pixel's target (wave-uniform geometry, per-lane flow): cells are laid over f1 shifted by one cell so that targets up
+// to a cell outside the image keep their neighbours; a pixel none of whose 10 x 10 positions can lie inside goes to the last cell
+__device__ __forceinline__ int k4s_cell(int bx, int by, int h, int w, int cx, int cy) {
+    const bool nothing = bx + K4M_N1 - 1 - K4M_RADIUS < 0 || bx - K4M_RADIUS >= w || by + K4M_N1 - 1 - K4M_RADIUS < 0 || by - K4M_RADIUS >= h;
+    if (nothing) return cx * cy;
+    const int ix = min(max((bx + K4S_CW) / K4S_CW, 0), cx - 1), iy = min(max((by + K4S_CH) / K4S_CH, 0), cy - 1);
+    return iy * cx + ix;
+}
+
+// prefix sum of the groups' tile counts + the mode decision: run by ONE workgroup (the last census block to finish)
+__device__ __forceinline__ void k4s_scan(unsigned* ctl, const unsigned* hist, unsigned* base, unsigned* cursor, int* perm, int ngroups,
+                                         unsigned natural_tiles, unsigned* part /* [256] LDS */, unsigned* total_s /* LDS */) {
+    const int tid = threadIdx.x;
+    // (the counters were raised by agent-scope atomics of workgroups on every XCD: read them the same way, not through this XCD's L2)
+    auto ld = [](const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const bool sorted = ld(ctl + 2) * 4u > natural_tiles;               // more than a quarter of the natural tiles incoherent
+    const int per = (ngroups + 255) / 256;
+    unsigned sum = 0;
+    for (int i = tid * per; i < min(ngroups, (tid + 1) * per); ++i) sum += (ld(hist + i) + 31) / 32;
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const unsigned v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total_s = run;
+        ctl[0] = sorted ? 1u : 0u;
+        ctl[1] = sorted ? run : 0u;
+    }
+    __syncthreads();
+    unsigned run = part[tid];
+    for (int i = tid * per; i < min(ngroups, (tid + 1) * per); ++i) {
+        base[i] = run;
+        cursor[i] = 0u;
+        run += (ld(hist + i) + 31) / 32;
+    }
+    if (sorted)
+        for (unsigned i = tid; i < *total_s * 32u; i += 256) perm[i] = -1;
+}
+
+// census + histogram (one thread per pixel, one natural 8 x 4 tile per 32 consecutive threads); the last block to finish scans
+__global__ __launch_bounds__(256) void k4s_census_kernel(const float* flow, int batch, int h, int w, int cx, int cy, unsigned* ctl,
+                                                         unsigned* hist, int* cell_of, unsigned* base, unsigned* cursor, int* perm, int ngroups,
+                                                         unsigned natural_tiles) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned total_s, ticket_s;
+    const int L = h * w, tiles_x = w / K4M_TW;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;            // (natural tile, slot) enumeration
+    const long tile = t >> 5;
+    const int n = (int)(t & 31);
+    if (tile < (long)batch * (L / 32)) {
+        const int b = (int)(tile / (L / 32)), tt = (int)(tile - (long)b * (L / 32));
+        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int x = tx * K4M_TW + (n & 7), y = ty * K4M_TH + (n >> 3), p = y * w + x;
+        const float fbx = floorf((float)x + flow[((long)b * 2 + 0) * L + p]), fby = floorf((float)y + flow[((long)b * 2 + 1) * L + p]);
+        const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f), by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
+        // the natural tile's window, as k4m_kernel computes it (the 32 lanes of one half-wave hold one tile here)
+        int x0 = bx, x1 = bx, y0 = by, y1 = by;
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) {
+            x0 = min(x0, __shfl_xor(x0, s));
+            x1 = max(x1, __shfl_xor(x1, s));
+            y0 = min(y0, __shfl_xor(y0, s));
+            y1 = max(y1, __shfl_xor(y1, s));
+        }
+        const bool coherent = x1 - x0 + K4M_N1 <= 32 && y1 - y0 + K4M_N1 <= K4M_MAXROWS;
+        unsigned seen = 0;                                           // results of this lane's atomics: waited for below
+        if (n == 0 && !coherent) seen += atomicAdd(ctl + 2, 1u);
+        const int cell = b * (cx * cy + 1) + k4s_cell(bx, by, h, w, cx, cy);
+        cell_of[(long)b * L + p] = cell;
+        // one atomic per DISTINCT cell of the wave (coherent flow: one or two; 98 k single atomics cost the launch ~50 us)
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c0 = __shfl(cell, leader);
+            const unsigned long long same = __ballot(cell == c0) & todo;
+            if ((int)(threadIdx.x & 63) == leader) seen += atomicAdd(hist + c0, (unsigned)__popcll(same));
+            todo &= ~same;
+        }
+        // hand-over without an agent-scope fence (that would write back the XCD's L2): the atomics RETURN, so each has been performed
+        // when its result is here; the ticket is taken behind the barrier; the last arriver reads the counters with agent-scope loads
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ticket_s = atomicAdd(ctl + 3, 1u);
+    __syncthreads();
+    if (ticket_s != gridDim.x - 1) return;
+    k4s_scan(ctl, hist, base, cursor, perm, ngroups, natural_tiles, part, &total_s);
+}
+
+// pixel ids into their groups (sorted mode), and the histogram / census words back to zero for the next launch (always): the
+// scratch is zero when the feature planes are built (um_local_corr_feat_planes) and every launch leaves it zero
+__global__ __launch_bounds__(256) void k4s_scatter_kernel(const unsigned* ctl, const int* cell_of, const unsigned* base, unsigned* cursor, int* perm,
+                                                          long rows, unsigned* hist, int ngroups) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < ngroups) hist[i] = 0u;
+    if (i == 0) {
+        const_cast<unsigned*>(ctl)[2] = 0u;
+        const_cast<unsigned*>(ctl)[3] = 0u;
+    }
+    if (ctl[0] == 0u) return;
+    if (i >= rows) return;
+    const int cell = cell_of[i];
+    const unsigned pos = atomicAdd(cursor + cell, 1u);
+    perm[(long)base[cell] * 32 + pos] = (int)i;
+}
+
 
 __device__ __forceinline__ int k4m_wave_min(int v) {
 #pragma unroll
@@ -69,22 +224,37 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
     // paths are bound by L2 -> CU traffic and lose with more waves in flight (2-3 waves per SIMD: pixel path +6...+20 %).
     __shared__ float dots_s[2][(K4M_N1 * K4M_N1 + 1) * 32];
     __shared__ float pix_s[2][K4M_N1 * K4M_N1 + 4];              // VALU path: the dot table of one pixel
+    __shared__ int pid_s[2][32];                                  // the tile's pixel ids (b * L + p; -1: empty slot of a sorted group)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, n = lane & 31;
     const int L = a.h * a.w;
     const int tiles_x = a.w / K4M_TW, tiles_y = a.h / K4M_TH;
-    const int ntile = a.batch * tiles_x * tiles_y;
+    const bool sorted = a.ctl != nullptr && a.ctl[0] != 0u;      // target-ordered groups instead of the natural tiles (uniform)
+    const int ntile = sorted ? (int)a.ctl[1] : a.batch * tiles_x * tiles_y;
     const float scale = 1.0f / sqrtf((float)UM_CHANNELS);
     float* dots = dots_s[wave];
     float* outt = dots_s[wave];
 
     for (int tile = blockIdx.x * 2 + wave; tile < ntile; tile += gridDim.x * 2) {
-        const int b = tile / (tiles_x * tiles_y);
-        const int tt = tile - b * (tiles_x * tiles_y);
-        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-        const int x = tx * K4M_TW + (n & 7), y = ty * K4M_TH + (n >> 3);
-        const int p = y * a.w + x;
+        // this lane's pixel: slot n of the natural 8 x 4 tile, or slot n of a sorted group (an empty slot borrows slot 0's pixel
+        // -- every group's first slot is taken -- and writes nothing)
+        int pid;
+        if (sorted) {
+            pid = a.perm[(long)tile * 32 + n];
+        } else {
+            const int bb = tile / (tiles_x * tiles_y);
+            const int tt = tile - bb * (tiles_x * tiles_y);
+            const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+            pid = bb * L + (ty * K4M_TH + (n >> 3)) * a.w + tx * K4M_TW + (n & 7);
+        }
+        const bool live = pid >= 0;
+        if (half == 0) pid_s[wave][n] = pid;
+        const int pid0 = __shfl(pid, 0);
+        if (!live) pid = pid0;
+        const int b = pid0 / L;                                               // one image per tile: groups are per image
+        const int p = pid - b * L;
+        const int y = p / a.w, x = p - y * a.w;
         const bool softmax_mode = a.flow_out != nullptr;                      // uniform
         const int n1 = softmax_mode ? K4M_KW : K4M_N1;                        // integer neighbourhood: 9 x 9 (no blend) or 10 x 10
         const float px = (float)x + (softmax_mode ? 0.f : a.flow[((long)b * 2 + 0) * L + p]);
@@ -99,8 +269,15 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
         const int bw = ux1 - ux0 + 1, bh = uy1 - uy0 + 1;
         const bool coherent = softmax_mode || (!a.force_valu && bw <= 32 && bh <= K4M_MAXROWS);     // wave uniform
 
-        if (a.stats && lane == 0) atomicAdd(a.stats + (coherent ? 0 : 1), 1u);
-        if (coherent) {
+        // a tile none of whose pixels can sample inside the image (flows that leave the map: a quarter of all pixels at random init;
+        // the sorted walk collects them in groups of their own) is all zeros (matching.py:113, zeros padding): no loads, no products
+        const bool off_image = !softmax_mode && (bx + K4M_N1 - 1 - K4M_RADIUS < 0 || bx - K4M_RADIUS >= a.w ||
+                                                 by + K4M_N1 - 1 - K4M_RADIUS < 0 || by - K4M_RADIUS >= a.h);
+        const bool all_off = __all(off_image);                                                        // wave uniform
+        if (a.stats && lane == 0) atomicAdd(a.stats + ((coherent || all_off) ? 0 : 1), 1u);
+        if (all_off) {
+            for (int idx = lane; idx < K4M_TAPS * 32; idx += 64) outt[idx] = 0.f;
+        } else if (coherent) {
             // ---- B operand: the tile's 32 pixels (f0), both planes
             i16x8 qf[2][8];
             {
@@ -224,6 +401,7 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
             // of 4 so that a load covers 64 contiguous bytes per slot (as local_ops.hip)
             const int slot = lane >> 2, quarter = lane & 3;
             for (int j = 0; j < 32; ++j) {
+                if (__shfl(live ? 1 : 0, j) == 0) continue;                   // empty slot of a sorted group (uniform)
                 const int jbx = __shfl(bx, j), jby = __shfl(by, j);
                 const float jwx = __shfl(wx, j), jwy = __shfl(wy, j);
                 const int jp = __shfl(p, j);
@@ -271,25 +449,26 @@ __global__ __launch_bounds__(128) void k4m_kernel(K4mArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- output: the [81][32] tile of this wave
-        const long pix0 = (long)b * L;
+        // ---- output: the [81][32] tile of this wave, every slot to its own pixel
         if (a.planes) {
             // channels-last operand planes for um_conv2d_ex: pixel row = ld channels, taps first, zeros up to ld
             const int pairs = a.ld >> 1;
             for (int idx = lane; idx < pairs * 32; idx += 64) {
                 const int j = idx / pairs, c = (idx - j * pairs) * 2;
-                const long pid = pix0 + (long)(ty * K4M_TH + (j >> 3)) * a.w + tx * K4M_TW + (j & 7);
+                const long pidj = pid_s[wave][j];
+                if (pidj < 0) continue;
                 const float v0 = c < K4M_TAPS ? outt[c * 32 + j] : 0.f, v1 = c + 1 < K4M_TAPS ? outt[(c + 1) * 32 + j] : 0.f;
                 const unsigned hh = Fp16::pack2(v0, v1);
                 const f32x2 u = Fp16::unpack2(hh);
-                *reinterpret_cast<unsigned*>(a.planes + pid * a.ld + c) = hh;
-                *reinterpret_cast<unsigned*>(a.planes + a.out_plane_stride + pid * a.ld + c) = Fp16::pack2(v0 - u[0], v1 - u[1]);
+                *reinterpret_cast<unsigned*>(a.planes + pidj * a.ld + c) = hh;
+                *reinterpret_cast<unsigned*>(a.planes + a.out_plane_stride + pidj * a.ld + c) = Fp16::pack2(v0 - u[0], v1 - u[1]);
             }
         } else {
             for (int idx = lane; idx < K4M_TAPS * 32; idx += 64) {
                 const int k = idx >> 5, j = idx & 31;
-                const int pp = (ty * K4M_TH + (j >> 3)) * a.w + tx * K4M_TW + (j & 7);
-                a.cost[((long)b * K4M_TAPS + k) * L + pp] = outt[k * 32 + j];
+                const int pidj = pid_s[wave][j];
+                if (pidj < 0) continue;
+                a.cost[((long)b * K4M_TAPS + k) * L + (pidj - b * L)] = outt[k * 32 + j];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -303,7 +482,7 @@ static size_t k4m_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // bytes of the feature planes of one scale: [f0 | f1], each [2][B * L][128] fp16
 extern "C" size_t um_local_corr_feat_planes_bytes(int batch, int h, int w, int channels) {
     if (batch <= 0 || h <= 0 || w <= 0 || channels != UM_CHANNELS) return 0;
-    return 2 * k4m_align256(planes_bytes((long)batch * h * w, 0));
+    return 2 * k4m_align256(planes_bytes((long)batch * h * w, 0)) + k4s_layout(batch, h, w).bytes;     // + target-ordering scratch
 }
 
 // split f0, f1 ([B, h*w, 128] fp32 tokens) into the operand planes the matrix-core cost volume reads; once per scale
@@ -320,6 +499,9 @@ extern "C" int um_local_corr_feat_planes(const float* f0, const float* f1, void*
     if ((e = launch_split_planes(f0, (unsigned short*)ws, rows, 1.f, 0, stream)) != hipSuccess) return (int)e;
     if ((e = launch_split_planes(f1, (unsigned short*)(ws + k4m_align256(planes_bytes(rows, 0))), rows, 1.f, 0, stream)) != hipSuccess)
         return (int)e;
+    // the target-ordering scratch behind the planes: census words and histogram start at zero (every launch leaves them zero)
+    const K4sLayout l = k4s_layout(batch, h, w);
+    if ((e = hipMemsetAsync(ws + 2 * k4m_align256(planes_bytes(rows, 0)), 0, l.off_base, stream)) != hipSuccess) return (int)e;
     return 0;
 }
 
@@ -367,14 +549,31 @@ extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, co
     a.force_valu = flags & 1;
     a.flow_out = nullptr;
     a.stats = stats;
+    a.perm = nullptr;
+    a.ctl = nullptr;
     const long ntile = rows / 32;
+    ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
+    if (!(flags & (1 | 2))) {
+        // target-ordered mode (flags bit 1 switches it off: A/B timing): census + histogram, scan, scatter -- all on device, the
+        // choice between natural tiles and sorted groups is made there from this call's flow alone
+        const K4sLayout l = k4s_layout(batch, h, w);
+        unsigned char* sc = (unsigned char*)feat_planes + 2 * k4m_align256(planes_bytes(rows, 0));
+        unsigned* ctl = (unsigned*)(sc + l.off_ctl);
+        unsigned* hist = (unsigned*)(sc + l.off_hist);
+        const size_t nb = (size_t)batch * l.ncell;
+        hipLaunchKernelGGL(k4s_census_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, flow, batch, h, w, l.cx, l.cy, ctl, hist,
+                           (int*)(sc + l.off_cell), (unsigned*)(sc + l.off_base), (unsigned*)(sc + l.off_cursor), (int*)(sc + l.off_perm), (int)nb,
+                           (unsigned)ntile);
+        hipLaunchKernelGGL(k4s_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ctl, (const int*)(sc + l.off_cell),
+                           (const unsigned*)(sc + l.off_base), (unsigned*)(sc + l.off_cursor), (int*)(sc + l.off_perm), rows, hist, (int)nb);
+        a.perm = (const int*)(sc + l.off_perm);
+        a.ctl = ctl;
+    }
+    // (the sorted walk has at most rows / 32 + groups tiles; the grid is the natural one either way, tiles are grid-strided)
     long blocks = (ntile + 1) / 2;
     if (blocks > 4096) blocks = 4096;
-    {
-        ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
-        um_census_hit(UM_V_K4_MFMA);
-        hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
-    }
+    um_census_hit(UM_V_K4_MFMA);
+    hipLaunchKernelGGL(k4m_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -415,6 +614,8 @@ extern "C" int um_local_corr_softmax_mfma(const float* f0, const float* f1, floa
     a.force_valu = 0;
     a.flow_out = out;
     a.stats = nullptr;
+    a.perm = nullptr;
+    a.ctl = nullptr;
     const long ntile = rows / 32;
     long blocks = (ntile + 1) / 2;
     if (blocks > 4096) blocks = 4096;
