@@ -136,6 +136,9 @@ __device__ __forceinline__ void ffn_dma16(const void* base, unsigned byte_off, c
 #else
 #define UM_FFN_ST(p, v) (*(p) = (v))
 #endif
+#ifndef UM_FFN_ROWSTORE
+#define UM_FFN_ROWSTORE 1
+#endif
 #ifndef UM_FFN_ABL
 #define UM_FFN_ABL 0     // timing ablations (results are wrong when non-zero): 1 gelu, 2 dma, 4 phase A, 8 phase B, 16 exchange, 32 residual read
 #endif
@@ -1066,6 +1069,41 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         }
     half_wave_pair(s2, u, v2);
     const float rstd = 1.0f / sqrtf((u + v2) * (1.0f / 128.0f) + a.eps);
+#if UM_FFN_ROWSTORE
+    if (role == 0) {
+        // lane holds, for its token, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot).  The tile leaves through LDS as
+        // WHOLE ROWS (round 5): a store instruction of the row-per-lane form touches 32 separate 32-byte pieces, and the tail of 16 of
+        // them per lane is store-issue-bound (MI355X_MICROARCH.md: ~9 k cycles per workgroup, exposed here -- one workgroup per CU);
+        // transposed, an instruction writes two 512-byte rows.  Staging: the pair's own exchange block (16 KB, consumed above), 16-byte
+        // chunk c of row r at c ^ r: the writes (8 rows per lane group) and the reads (32 chunks of a row) are conflict free.
+        unsigned char* stg = lds + (KV4 ? 65536 : 0) + pair * 16384;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * ot + 8 * g;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + n + 4 * half);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + n + 4 * half);
+                f32x4 yv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yv[i] = (o[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i] + rr[4 * ot + g][i];
+                *reinterpret_cast<f32x4*>(stg + tl * 512 + (((8 * ot + 2 * g + half) ^ tl) << 4)) = yv;
+                if constexpr (KV4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[ot][4 * g + i] = yv[i];
+                }
+            }
+        __builtin_amdgcn_wave_barrier();                            // same wave: LDS executes its accesses in order
+        const int cc = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = 2 * j + half;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * 512 + ((cc ^ r) << 4));
+            const int trow = m0 + 32 * pair + r;
+            if (trow < a.M) UM_FFN_ST(reinterpret_cast<f32x4*>(a.out + (long)trow * 128 + 4 * cc), v);
+        }
+    }
+#else       // round 1-4: every lane stores its own token's 16-byte pieces (diagnostic builds: -DUM_FFN_ROWSTORE=0)
     if (KV4 ? role == 0 : tok < a.M) {
         // lane holds, for its token, features 32 ot + 8 g + 4 half + i  (reg 4 g + i of tile ot)
         const int tokc = min(tok, a.M - 1);                         // (KV4: rows past M are computed on a valid row and never stored)
@@ -1087,6 +1125,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 }
             }
     }
+#endif
     if constexpr (KV4) {
         // ---- the next block's k | v projections of this tile (kv4_project): Y^T operand fragments from the normalised tile exactly as
         // the stand-alone kernel builds them from the fp32 tokens it reads back (same hi | lo split of the same fp32 values), handed to

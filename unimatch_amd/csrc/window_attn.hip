@@ -774,6 +774,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     um_range_note<T>(a.range_flag, omx, UM_RANGE_ATTN_OUTPUT);
+    // the residual rows are requested HERE, the merge GEMM ahead of their use (the accumulators' 64 registers are free since the
+    // conversion above): their latency was exposed at the very end of the workgroup
+    f32x4 rres[16];
+    if (a.residual != nullptr && tq < a.n) {
+        const float* rb0 = a.residual + (sbase + tokq) * UM_CHANNELS + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rres[q] = *reinterpret_cast<const f32x4*>(rb0 + 8 * q);
+    }
     f32x16 yv[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
@@ -831,9 +839,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = (yv[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i];
                 if (rb) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rb + n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] += rr[i];
+                    for (int i = 0; i < 4; ++i) y[i] += rres[4 * ot + g][i];
                 }
                 *reinterpret_cast<f32x4*>(ob + n) = y;
             }
