@@ -101,6 +101,39 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
     const int nb = n0 + 32 * NT0;                                 // first output channel of the pass
     unsigned char* stg = lds + wave * WSTRIDE;                    // same block in every pass: waves are not synchronised
     const int tl = lane & 31;
+    // ---- side tensors of the pass's rows (addend, gate z / h): REQUESTED before they are needed.  h is updated in place and nothing
+    // here is __restrict__, so a load written after a store waits for it: one exposed round trip to HBM per iteration and wave with
+    // the matrix pipes idle (the hoisted GRU gates of config 4 spent a fifth of their launches like that).  Batch 0 is requested before
+    // the transpose below; with 128-wide tiles (one workgroup of <= 256 registers per lane) batch b + 1 is requested before batch b is used.
+    constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
+    constexpr int ITER = 32 * CPR / 64;
+    constexpr int BATCH = ITER < 4 ? ITER : 4, NBATCH = ITER / BATCH, NSIDE = NT == 4 ? 2 : 1;
+    static_assert(ITER % BATCH == 0, "batches cover the iterations");
+    const long rowbase = (long)bt * P + rloc0;                    // first output row of this wave
+    const int nrows = nvalid;                                     // valid rows (0: none)
+    const int gate = a.gate;
+    float* hbase = gate ? a.gate_h + rowbase * a.gate_c : nullptr;
+    const float* zbase = gate == 2 ? a.gate_z + rowbase * a.gate_zld : nullptr;
+    const float* abase = a.addend ? a.addend + rowbase * a.addend_ld : nullptr;
+    f32x4 ad[NSIDE][BATCH], gz[NSIDE][BATCH], gh[NSIDE][BATCH];
+    auto preload = [&](int b, int slot) {                         // both compile-time constants once the callers' loops are unrolled
+        if (!abase && !gate) return;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int idx = (b * BATCH + j) * 64 + lane;
+            const int r = idx / CPR, c = idx - r * CPR;
+            const int col = nb + 4 * c;
+            if (r < nrows && col < a.Cout) {
+                if (abase) ad[slot][j] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(r * a.addend_ld + col));
+                if (gate == 1 && col >= a.gate_c) gh[slot][j] = *reinterpret_cast<const f32x4*>(hbase + (unsigned)(r * a.gate_c + col - a.gate_c));
+                if (gate == 2) {
+                    gz[slot][j] = *reinterpret_cast<const f32x4*>(zbase + (unsigned)(r * a.gate_zld + col));
+                    gh[slot][j] = *reinterpret_cast<const f32x4*>(hbase + (unsigned)(r * a.gate_c + col));
+                }
+            }
+        }
+    };
+    preload(0, 0);
     auto to_lds = [&](auto act_tag, auto bias_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool BIAS = decltype(bias_tag)::value != 0;
@@ -134,7 +167,6 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         default: to_lds_b(IntC<3>{}); break;
     }
     __builtin_amdgcn_wave_barrier();
-    constexpr int CPR = 8 * NTP;                                  // 16-byte chunks per row
     if (a.stats) {
         // InstanceNorm statistics of the NEXT layer for free: column sums of the tile that is sitting in LDS anyway.
         // Per wave: its valid pixels (32 except in the ragged last tile of an image), shifted by the first one (no
@@ -207,68 +239,70 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
         }
     }
     // ---- full-row stores: wave-uniform 64-bit bases, 32-bit lane offsets
-    constexpr int ITER = 32 * CPR / 64;
-    const long rowbase = (long)bt * P + rloc0;                    // first output row of this wave
-    const int nrows = nvalid;                                     // valid rows (0: none)
-    auto store_rows = [&](auto gate_tag) {
+    auto store_rows = [&](auto gate_tag, auto add_tag) {
         constexpr int GATE = decltype(gate_tag)::value;
+        constexpr bool ADD = decltype(add_tag)::value != 0;
         float* obase = a.out ? a.out + rowbase * a.out_ld + a.out_coff : nullptr;
         unsigned short* pbase = a.outp ? a.outp + rowbase * a.outp_ld + a.outp_coff : nullptr;
-        float* hbase = GATE ? a.gate_h + rowbase * a.gate_c : nullptr;
-        const float* zbase = GATE == 2 ? a.gate_z + rowbase * a.gate_zld : nullptr;
-        const float* abase = a.addend ? a.addend + rowbase * a.addend_ld : nullptr;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int idx = it * 64 + lane;
-            const int r = idx / CPR, c = idx - r * CPR;
-            f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
-            int col = nb + 4 * c;
-            if (r < nrows && col < a.Cout) {
-                if (abase) {                                      // full-row reads, then the activation that waited for them
-                    d = d + *reinterpret_cast<const f32x4*>(abase + (unsigned)(r * a.addend_ld + col));
+        for (int b = 0; b < NBATCH; ++b) {
+            const int slot = NSIDE == 2 ? (b & 1) : 0;
+            if ((ADD || GATE != 0) && NSIDE == 2 && b + 1 < NBATCH) preload(b + 1, (b + 1) & 1);     // plain stores: one straight-line block
+            if ((ADD || GATE != 0) && NSIDE == 1 && b > 0) preload(b, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (a.act == 1) d[i] = fmaxf(d[i], 0.f);
-                        else if (a.act == 2) d[i] = 1.0f / (1.0f + __expf(-d[i]));
-                        else if (a.act == 3) d[i] = tanhf(d[i]);
+            for (int j = 0; j < BATCH; ++j) {
+                const int idx = (b * BATCH + j) * 64 + lane;
+                const int r = idx / CPR, c = idx - r * CPR;
+                f32x4 d = *reinterpret_cast<const f32x4*>(stg + r * ROWB + ((c ^ (r & 7)) << 4));
+                int col = nb + 4 * c;
+                if (r < nrows && col < a.Cout) {
+                    if (ADD) {                                    // full-row reads, then the activation that waited for them
+                        d = d + ad[slot][j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (a.act == 1) d[i] = fmaxf(d[i], 0.f);
+                            else if (a.act == 2) d[i] = 1.0f / (1.0f + __expf(-d[i]));
+                            else if (a.act == 3) d[i] = tanhf(d[i]);
+                        }
                     }
-                }
-                bool to_out = obase != nullptr, to_planes = pbase != nullptr;
-                if (GATE == 1) {
-                    if (col >= a.gate_c) {
-                        col -= a.gate_c;
-                        d = d * *reinterpret_cast<const f32x4*>(hbase + (unsigned)(r * a.gate_c + col));
-                        to_out = false;
-                    } else {
-                        to_planes = false;
-                    }
-                } else if (GATE == 2) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(zbase + (unsigned)(r * a.gate_zld + col));
-                    float* hp = hbase + (unsigned)(r * a.gate_c + col);
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hp);
+                    bool to_out = obase != nullptr, to_planes = pbase != nullptr;
+                    if (GATE == 1) {
+                        if (col >= a.gate_c) {
+                            col -= a.gate_c;
+                            d = d * gh[slot][j];
+                            to_out = false;
+                        } else {
+                            to_planes = false;
+                        }
+                    } else if (GATE == 2) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = (1.0f - z[i]) * hv[i] + z[i] * d[i];
-                    *reinterpret_cast<f32x4*>(hp) = d;
-                }
-                // streaming stores: the tile is next touched by another kernel; as ordinary stores these lines evicted the
-                // activation rows the neighbouring workgroups are about to re-read (+1.5 % end to end, same-box ABAB)
-                if (to_out) __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(obase + (unsigned)(r * a.out_ld + col)));
-                if (to_planes) {
-                    unsigned short* dst = pbase + (unsigned)(r * a.outp_ld + col);
-                    const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};     // planes feed the next convolution: ordinary stores
-                    if (NS == 2) {
-                        const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
-                        const u32x2 lo = u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
-                        *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) = lo;
+                        for (int i = 0; i < 4; ++i) d[i] = (1.0f - gz[slot][j][i]) * gh[slot][j][i] + gz[slot][j][i] * d[i];
+                        *reinterpret_cast<f32x4*>(hbase + (unsigned)(r * a.gate_c + col)) = d;
+                    }
+                    // streaming stores: the tile is next touched by another kernel; as ordinary stores these lines evicted the
+                    // activation rows the neighbouring workgroups are about to re-read (+1.5 % end to end, same-box ABAB)
+                    if (to_out) __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(obase + (unsigned)(r * a.out_ld + col)));
+                    if (to_planes) {
+                        unsigned short* dst = pbase + (unsigned)(r * a.outp_ld + col);
+                        const unsigned h0 = T::pack2(d[0], d[1]), h1 = T::pack2(d[2], d[3]);
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};     // planes feed the next convolution: ordinary stores
+                        if (NS == 2) {
+                            const f32x2 u0 = T::unpack2(h0), u1 = T::unpack2(h1);
+                            const u32x2 lo = u32x2{T::pack2(d[0] - u0[0], d[1] - u0[1]), T::pack2(d[2] - u1[0], d[3] - u1[1])};
+                            *reinterpret_cast<u32x2*>(dst + a.outp_plane_stride) = lo;
+                        }
                     }
                 }
             }
         }
     };
-    if (a.gate == 0) store_rows(IntC<0>{});
-    else if (a.gate == 1) store_rows(IntC<1>{});
-    else store_rows(IntC<2>{});
+    auto store_rows_g = [&](auto gate_tag) {
+        if (a.addend) store_rows(gate_tag, IntC<1>{});
+        else store_rows(gate_tag, IntC<0>{});
+    };
+    if (a.gate == 0) store_rows_g(IntC<0>{});
+    else if (a.gate == 1) store_rows_g(IntC<1>{});
+    else store_rows_g(IntC<2>{});
 }
 
 // NTE = n-tiles per epilogue pass (NT: the whole tile at once).
