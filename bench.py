@@ -489,7 +489,8 @@ def main():
                'note': 'mean end-point error in pixels at full resolution on 1 sample pair; the middle figure is '
                        'the fp32 reference-port noise floor at random-init weights.  Every sample of the batch, both image '
                        'kinds, 3 seeds, all five configs at their own batch: profiles/r03_parity_batch.txt; configs 3 / 4 (chaotic '
-                       'end to end at random init) stage by stage on the reference constructor\'s weights: profiles/r04_stage_parity.txt'}
+                       'end to end at random init) stage by stage on the reference constructor\'s weights: profiles/r04_stage_parity.txt; configs 1 / 2 / 5 stage by stage: '
+                       'profiles/r05_stage_parity_one_scale.txt'}
         if extra is not None:
             epe_other = round(_epe(extra[1][:1].cpu(), truth), 6)
         # the same port on this GPU with stock PyTorch-ROCm eager ops (factories default to the device inside the context)

@@ -24,8 +24,11 @@
 // has no common window: round 4 measured the pixel path at 20 x its compulsory bytes (2.1 GB per launch at 4 x 128 x 192) with
 // the waves parked 69 % of the time.  But pixels whose TARGETS lie in one 16 x 8 cell of f1 always share a 26 x 18 window,
 // wherever they sit in f0.  So a launch first takes a census of its natural tiles (k4s_census_kernel); if more than a quarter
-// of them are incoherent the pixels are counting-sorted by (image, target cell) -- histogram in the census, prefix sum by
-// the census' last block, scatter of pixel ids into per-cell groups padded to whole 32-pixel tiles (k4s_scatter_kernel) -- and
+// of them are incoherent the pixels are counting-sorted by (image, target cell) -- a few large workgroups each histogram their
+// share of the pixels in LDS and publish the counts, the last one to finish turns the [workgroup][cell] counts into start slots
+// (two-level prefix sum), and k4s_scatter_kernel's workgroups hand their pixels out from those slots with LDS atomics: no
+// global atomic per pixel or per cell anywhere (a first version had them: 98 k device-scope atomics on 32 cache lines made
+// census + scatter 153 us of the launch's 288) -- into per-cell groups padded to whole 32-pixel tiles, and
 // k4m_kernel walks those groups: lane = any pixel of the group, everything downstream (B operand, scatter addresses, blend
 // weights, output row) was per lane already.  Pixels whose whole neighbourhood misses the image go to one group that writes
 // zeros.  Properties kept: the decision is a pure function of the call's flow (no state, no host read-back); a pixel's 100 dot
@@ -71,10 +74,16 @@ struct K4mArgs {
 };
 
 // ---- scratch layout of the target-ordered mode (inside the feature-plane workspace, behind the planes)
+#define K4S_WG 1024              // threads of a sorting workgroup
+#define K4S_MAXG 32              // sorting workgroups per launch (the last one reads all their counts in one batch of loads)
+#define K4S_MAXGROUPS 15360      // (image, cell) groups whose counters fit a workgroup's LDS (60 KB); beyond: natural tiles only
 struct K4sLayout {
     int cx, cy, ncell;           // cells per image: (cx x cy) inside + 1 "nothing to sample" cell
     long rows;
-    size_t off_ctl, off_hist, off_base, off_cursor, off_cell, off_perm, bytes;
+    int ng;                      // sorting workgroups
+    long span;                   // (natural tile, slot) units per sorting workgroup: whole waves
+    bool ok;                     // the geometry can be target-ordered at all
+    size_t off_ctl, off_part, off_cell, off_perm, bytes;
 };
 static inline K4sLayout k4s_layout(int batch, int h, int w) {
     K4sLayout l;
@@ -83,13 +92,15 @@ static inline K4sLayout k4s_layout(int batch, int h, int w) {
     l.ncell = l.cx * l.cy + 1;
     l.rows = (long)batch * h * w;
     const size_t nb = (size_t)batch * l.ncell;
+    l.ok = nb <= K4S_MAXGROUPS;
+    l.ng = (int)((l.rows + K4S_WG - 1) / K4S_WG);
+    if (l.ng > K4S_MAXG) l.ng = K4S_MAXG;
+    l.span = ((l.rows + l.ng - 1) / l.ng + 63) & ~63L;
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
-    l.off_ctl = take(64);
-    l.off_hist = take(nb * 4);
-    l.off_base = take(nb * 4);
-    l.off_cursor = take(nb * 4);
-    l.off_cell = take((size_t)l.rows * 4);
+    l.off_ctl = take(64);                        // [0] mode, [1] sorted tiles, [2] incoherent natural tiles, [3] arrival ticket
+    l.off_part = take((size_t)K4S_MAXG * nb * 4);  // [workgroup][group]: counts, then start slots
+    l.off_cell = take((size_t)l.rows * 4);       // group of every pixel, in (natural tile, slot) order
     l.off_perm = take(((size_t)l.rows + 32 * nb) * 4);
     l.bytes = o;
     return l;
@@ -104,54 +115,120 @@ __device__ __forceinline__ int k4s_cell(int bx, int by, int h, int w, int cx, in
     return iy * cx + ix;
 }
 
-// prefix sum of the groups' tile counts + the mode decision: run by ONE workgroup (the last census block to finish)
-__device__ __forceinline__ void k4s_scan(unsigned* ctl, const unsigned* hist, unsigned* base, unsigned* cursor, int* perm, int ngroups,
-                                         unsigned natural_tiles, unsigned* part /* [256] LDS */, unsigned* total_s /* LDS */) {
-    const int tid = threadIdx.x;
-    // (the counters were raised by agent-scope atomics of workgroups on every XCD: read them the same way, not through this XCD's L2)
-    auto ld = [](const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    const bool sorted = ld(ctl + 2) * 4u > natural_tiles;               // more than a quarter of the natural tiles incoherent
-    const int per = (ngroups + 255) / 256;
-    unsigned sum = 0;
-    for (int i = tid * per; i < min(ngroups, (tid + 1) * per); ++i) sum += (ld(hist + i) + 31) / 32;
-    part[tid] = sum;
+// exclusive prefix sum over the 1024 threads of a sorting workgroup (wsum: 16 words of LDS; *total = the sum)
+__device__ __forceinline__ unsigned k4s_block_exscan(unsigned v, unsigned* wsum, unsigned* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned u = __shfl_up(inc, s);
+        if (lane >= s) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    if (tid == 0) {
-        unsigned run = 0;
-        for (int i = 0; i < 256; ++i) {
-            const unsigned v = part[i];
-            part[i] = run;
-            run += v;
+    if (wave == 0) {
+        const unsigned w = lane < K4S_WG / 64 ? wsum[lane] : 0u;
+        unsigned winc = w;
+#pragma unroll
+        for (int s = 1; s < K4S_WG / 64; s <<= 1) {
+            const unsigned u = __shfl_up(winc, s);
+            if (lane >= s) winc += u;
         }
-        *total_s = run;
-        ctl[0] = sorted ? 1u : 0u;
-        ctl[1] = sorted ? run : 0u;
+        if (lane < K4S_WG / 64) wsum[lane] = winc - w;
+        if (lane == K4S_WG / 64 - 1) *total = winc;
     }
     __syncthreads();
-    unsigned run = part[tid];
-    for (int i = tid * per; i < min(ngroups, (tid + 1) * per); ++i) {
-        base[i] = run;
-        cursor[i] = 0u;
-        run += (ld(hist + i) + 31) / 32;
-    }
-    if (sorted)
-        for (unsigned i = tid; i < *total_s * 32u; i += 256) perm[i] = -1;
+    return wsum[wave] + inc - v;
 }
 
-// census + histogram (one thread per pixel, one natural 8 x 4 tile per 32 consecutive threads); the last block to finish scans
-__global__ __launch_bounds__(256) void k4s_census_kernel(const float* flow, int batch, int h, int w, int cx, int cy, unsigned* ctl,
-                                                         unsigned* hist, int* cell_of, unsigned* base, unsigned* cursor, int* perm, int ngroups,
-                                                         unsigned natural_tiles) {
-    __shared__ unsigned part[256];
-    __shared__ unsigned total_s, ticket_s;
-    const int L = h * w, tiles_x = w / K4M_TW;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;            // (natural tile, slot) enumeration
+// (natural tile, slot) unit t -> image b, pixel p of the image, its coordinates
+__device__ __forceinline__ void k4s_pixel(long t, int L, int tiles_x, int w, int& b, int& p, int& x, int& y) {
     const long tile = t >> 5;
     const int n = (int)(t & 31);
-    if (tile < (long)batch * (L / 32)) {
-        const int b = (int)(tile / (L / 32)), tt = (int)(tile - (long)b * (L / 32));
-        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-        const int x = tx * K4M_TW + (n & 7), y = ty * K4M_TH + (n >> 3), p = y * w + x;
+    b = (int)(tile / (L / 32));
+    const int tt = (int)(tile - (long)b * (L / 32));
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    x = tx * K4M_TW + (n & 7);
+    y = ty * K4M_TH + (n >> 3);
+    p = y * w + x;
+}
+
+// Start slots from the published counts + the mode decision: run by ONE workgroup (the last census workgroup to finish).
+// part [ng][ngroups]: counts in, start slots (in pixels) out; tot_s [ngroups] LDS.
+__device__ __forceinline__ void k4s_scan(unsigned* ctl, unsigned* part, int* perm, int ngroups, int ng, unsigned natural_tiles,
+                                         unsigned* tot_s, unsigned* wsum, unsigned* total_s) {
+    const int tid = threadIdx.x;
+    // (the counts were published by workgroups on every XCD with agent-scope stores: read them the same way, not through this XCD's L2)
+    auto ld = [](const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const bool sorted = ld(ctl + 2) * 4u > natural_tiles;               // more than a quarter of the natural tiles incoherent
+    __syncthreads();                                                     // every thread has read the census word before it is reset
+    if (!sorted) {
+        if (tid == 0) {
+            ctl[0] = 0u;
+            ctl[1] = 0u;
+            ctl[2] = 0u;                                                 // census word and ticket back to zero for the next launch
+            ctl[3] = 0u;
+        }
+        return;
+    }
+    // a thread owns `per` consecutive groups; all of a group's ng counts are requested before the first is used
+    const int per = (ngroups + K4S_WG - 1) / K4S_WG;
+    const int c0 = tid * per, c1 = min(ngroups, c0 + per);
+    unsigned mine = 0;
+    for (int c = c0; c < c1; ++c) {
+        unsigned v[K4S_MAXG];
+#pragma unroll
+        for (int g = 0; g < K4S_MAXG; ++g) v[g] = g < ng ? ld(part + (long)g * ngroups + c) : 0u;
+        unsigned tot = 0;
+#pragma unroll
+        for (int g = 0; g < K4S_MAXG; ++g) tot += v[g];
+        tot_s[c] = tot;
+        mine += (tot + 31) / 32;
+    }
+    unsigned run = k4s_block_exscan(mine, wsum, total_s);               // first tile of this thread's first group
+    for (int c = c0; c < c1; ++c) {
+        unsigned v[K4S_MAXG];
+#pragma unroll
+        for (int g = 0; g < K4S_MAXG; ++g) v[g] = g < ng ? ld(part + (long)g * ngroups + c) : 0u;
+        const unsigned tot = tot_s[c];
+        unsigned at = run * 32u;
+#pragma unroll
+        for (int g = 0; g < K4S_MAXG; ++g)
+            if (g < ng) {
+                part[(long)g * ngroups + c] = at;                        // read by the scatter kernel (next launch on the stream)
+                at += v[g];
+            }
+        run += (tot + 31) / 32;
+        for (unsigned sl = at; sl < run * 32u; ++sl) perm[sl] = -1;      // the padding of the group's last tile
+    }
+    if (tid == 0) {
+        ctl[0] = 1u;
+        ctl[1] = *total_s;
+        ctl[2] = 0u;
+        ctl[3] = 0u;
+    }
+}
+
+// census of the natural tiles + per-workgroup histogram of the pixels' groups (grid = ng workgroups of 1024 threads, each owning a
+// contiguous span of (natural tile, slot) units: one natural 8 x 4 tile per 32 consecutive threads); the last workgroup scans
+__global__ __launch_bounds__(K4S_WG) void k4s_census_kernel(const float* flow, int batch, int h, int w, int cx, int cy, unsigned* ctl,
+                                                            unsigned* part, int* cell_t, int* perm, int ngroups, long span,
+                                                            unsigned natural_tiles) {
+    extern __shared__ unsigned hist_s[];                                 // [ngroups]
+    __shared__ unsigned wsum[K4S_WG / 64];
+    __shared__ unsigned total_s, ticket_s, incoh_s;
+    const int tid = threadIdx.x;
+    const int L = h * w, tiles_x = w / K4M_TW;
+    const long rows = (long)batch * L;
+    for (int i = tid; i < ngroups; i += K4S_WG) hist_s[i] = 0u;
+    if (tid == 0) incoh_s = 0u;
+    __syncthreads();
+    const long t0 = (long)blockIdx.x * span, t1 = min(t0 + span, rows);
+    for (long base = t0; base < t1; base += K4S_WG) {                    // (spans and rows are whole half-waves: a natural tile is never split)
+        const long t = base + tid;
+        const bool active = t < t1;
+        int b, p, x, y;
+        k4s_pixel(active ? t : t1 - 1, L, tiles_x, w, b, p, x, y);
         const float fbx = floorf((float)x + flow[((long)b * 2 + 0) * L + p]), fby = floorf((float)y + flow[((long)b * 2 + 1) * L + p]);
         const int bx = (int)fminf(fmaxf(fbx, -32768.f), 32768.f), by = (int)fminf(fmaxf(fby, -32768.f), 32768.f);
         // the natural tile's window, as k4m_kernel computes it (the 32 lanes of one half-wave hold one tile here)
@@ -163,46 +240,48 @@ __global__ __launch_bounds__(256) void k4s_census_kernel(const float* flow, int 
             y0 = min(y0, __shfl_xor(y0, s));
             y1 = max(y1, __shfl_xor(y1, s));
         }
-        const bool coherent = x1 - x0 + K4M_N1 <= 32 && y1 - y0 + K4M_N1 <= K4M_MAXROWS;
-        unsigned seen = 0;                                           // results of this lane's atomics: waited for below
-        if (n == 0 && !coherent) seen += atomicAdd(ctl + 2, 1u);
-        const int cell = b * (cx * cy + 1) + k4s_cell(bx, by, h, w, cx, cy);
-        cell_of[(long)b * L + p] = cell;
-        // one atomic per DISTINCT cell of the wave (coherent flow: one or two; 98 k single atomics cost the launch ~50 us)
-        unsigned long long todo = __ballot(1);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int c0 = __shfl(cell, leader);
-            const unsigned long long same = __ballot(cell == c0) & todo;
-            if ((int)(threadIdx.x & 63) == leader) seen += atomicAdd(hist + c0, (unsigned)__popcll(same));
-            todo &= ~same;
+        if (active) {
+            const bool coherent = x1 - x0 + K4M_N1 <= 32 && y1 - y0 + K4M_N1 <= K4M_MAXROWS;
+            if ((t & 31) == 0 && !coherent) atomicAdd(&incoh_s, 1u);
+            const int cell = b * (cx * cy + 1) + k4s_cell(bx, by, h, w, cx, cy);
+            cell_t[t] = cell;
+            atomicAdd(hist_s + cell, 1u);
         }
-        // hand-over without an agent-scope fence (that would write back the XCD's L2): the atomics RETURN, so each has been performed
-        // when its result is here; the ticket is taken behind the barrier; the last arriver reads the counters with agent-scope loads
-        asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");
     }
     __syncthreads();
-    if (threadIdx.x == 0) ticket_s = atomicAdd(ctl + 3, 1u);
+    // publish without an agent-scope fence (that would write back the XCD's L2): agent-scope stores, waited for; the census word's atomic
+    // RETURNS, so it has been performed when its result is here; the ticket is taken behind the barrier; the last arriver reads everything
+    // with agent-scope loads
+    for (int i = tid; i < ngroups; i += K4S_WG)
+        __hip_atomic_store(part + (long)blockIdx.x * ngroups + i, hist_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned seen = 0;
+    if (tid == 0 && incoh_s) seen = atomicAdd(ctl + 2, incoh_s);
+    asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");
+    __syncthreads();
+    if (tid == 0) ticket_s = atomicAdd(ctl + 3, 1u);
     __syncthreads();
     if (ticket_s != gridDim.x - 1) return;
-    k4s_scan(ctl, hist, base, cursor, perm, ngroups, natural_tiles, part, &total_s);
+    k4s_scan(ctl, part, perm, ngroups, (int)gridDim.x, natural_tiles, hist_s, wsum, &total_s);
 }
 
-// pixel ids into their groups (sorted mode), and the histogram / census words back to zero for the next launch (always): the
-// scratch is zero when the feature planes are built (um_local_corr_feat_planes) and every launch leaves it zero
-__global__ __launch_bounds__(256) void k4s_scatter_kernel(const unsigned* ctl, const int* cell_of, const unsigned* base, unsigned* cursor, int* perm,
-                                                          long rows, unsigned* hist, int ngroups) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < ngroups) hist[i] = 0u;
-    if (i == 0) {
-        const_cast<unsigned*>(ctl)[2] = 0u;
-        const_cast<unsigned*>(ctl)[3] = 0u;
-    }
+// pixel ids into their groups (sorted mode only): the workgroups of the census, over the same spans, hand their pixels out from their
+// start slots with LDS atomics.  (The order inside a group depends on the order of those atomics; the result of k4m_kernel does not.)
+__global__ __launch_bounds__(K4S_WG) void k4s_scatter_kernel(const unsigned* ctl, const int* cell_t, const unsigned* part, int* perm,
+                                                             int batch, int h, int w, int ngroups, long span) {
+    extern __shared__ unsigned cursor_s[];                               // [ngroups]
     if (ctl[0] == 0u) return;
-    if (i >= rows) return;
-    const int cell = cell_of[i];
-    const unsigned pos = atomicAdd(cursor + cell, 1u);
-    perm[(long)base[cell] * 32 + pos] = (int)i;
+    const int tid = threadIdx.x;
+    const int L = h * w, tiles_x = w / K4M_TW;
+    const long rows = (long)batch * L;
+    for (int i = tid; i < ngroups; i += K4S_WG) cursor_s[i] = part[(long)blockIdx.x * ngroups + i];
+    __syncthreads();
+    const long t0 = (long)blockIdx.x * span, t1 = min(t0 + span, rows);
+    for (long t = t0 + tid; t < t1; t += K4S_WG) {
+        int b, p, x, y;
+        k4s_pixel(t, L, tiles_x, w, b, p, x, y);
+        const unsigned pos = atomicAdd(cursor_s + cell_t[t], 1u);
+        perm[pos] = b * L + p;
+    }
 }
 
 
@@ -499,9 +578,9 @@ extern "C" int um_local_corr_feat_planes(const float* f0, const float* f1, void*
     if ((e = launch_split_planes(f0, (unsigned short*)ws, rows, 1.f, 0, stream)) != hipSuccess) return (int)e;
     if ((e = launch_split_planes(f1, (unsigned short*)(ws + k4m_align256(planes_bytes(rows, 0))), rows, 1.f, 0, stream)) != hipSuccess)
         return (int)e;
-    // the target-ordering scratch behind the planes: census words and histogram start at zero (every launch leaves them zero)
+    // the target-ordering scratch behind the planes: the census word and the ticket start at zero (every launch leaves them zero)
     const K4sLayout l = k4s_layout(batch, h, w);
-    if ((e = hipMemsetAsync(ws + 2 * k4m_align256(planes_bytes(rows, 0)), 0, l.off_base, stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws + 2 * k4m_align256(planes_bytes(rows, 0)), 0, l.off_part, stream)) != hipSuccess) return (int)e;
     return 0;
 }
 
@@ -553,19 +632,18 @@ extern "C" int um_local_corr_with_flow_feat(const float* f0, const float* f1, co
     a.ctl = nullptr;
     const long ntile = rows / 32;
     ScopedKernelTimer timer(UM_K_COST_VOLUME, stream);
-    if (!(flags & (1 | 2))) {
-        // target-ordered mode (flags bit 1 switches it off: A/B timing): census + histogram, scan, scatter -- all on device, the
-        // choice between natural tiles and sorted groups is made there from this call's flow alone
-        const K4sLayout l = k4s_layout(batch, h, w);
+    const K4sLayout l = k4s_layout(batch, h, w);
+    if (!(flags & (1 | 2)) && l.ok) {
+        // target-ordered mode (flags bit 1 switches it off: A/B timing): census + per-workgroup histograms, start slots, scatter -- all on
+        // device, the choice between natural tiles and sorted groups is made there from this call's flow alone
         unsigned char* sc = (unsigned char*)feat_planes + 2 * k4m_align256(planes_bytes(rows, 0));
         unsigned* ctl = (unsigned*)(sc + l.off_ctl);
-        unsigned* hist = (unsigned*)(sc + l.off_hist);
-        const size_t nb = (size_t)batch * l.ncell;
-        hipLaunchKernelGGL(k4s_census_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, flow, batch, h, w, l.cx, l.cy, ctl, hist,
-                           (int*)(sc + l.off_cell), (unsigned*)(sc + l.off_base), (unsigned*)(sc + l.off_cursor), (int*)(sc + l.off_perm), (int)nb,
-                           (unsigned)ntile);
-        hipLaunchKernelGGL(k4s_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ctl, (const int*)(sc + l.off_cell),
-                           (const unsigned*)(sc + l.off_base), (unsigned*)(sc + l.off_cursor), (int*)(sc + l.off_perm), rows, hist, (int)nb);
+        unsigned* part = (unsigned*)(sc + l.off_part);
+        const int nb = batch * l.ncell;
+        hipLaunchKernelGGL(k4s_census_kernel, dim3((unsigned)l.ng), dim3(K4S_WG), (size_t)nb * 4, stream, flow, batch, h, w, l.cx, l.cy, ctl, part,
+                           (int*)(sc + l.off_cell), (int*)(sc + l.off_perm), nb, l.span, (unsigned)ntile);
+        hipLaunchKernelGGL(k4s_scatter_kernel, dim3((unsigned)l.ng), dim3(K4S_WG), (size_t)nb * 4, stream, ctl, (const int*)(sc + l.off_cell),
+                           (const unsigned*)part, (int*)(sc + l.off_perm), batch, h, w, nb, l.span);
         a.perm = (const int*)(sc + l.off_perm);
         a.ctl = ctl;
     }
