@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define UM_VERSION 210
+#define UM_VERSION 211
 
 #define UM_MODE_EXACT 0
 #define UM_MODE_FAST 1
@@ -289,7 +289,9 @@ int um_conv2d_gru_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long
  * channels for gate 2), added to the scaled accumulator (+ bias) BEFORE the gate's activation.  A convolution is linear in its input
  * channels: the refinement loop (unimatch/unimatch.py:315-331) restarts its hidden state from the same net0 and feeds the same
  * context features `inp` in every iteration, so their share of every gate convolution is computed ONCE per scale (um_conv2d_ex,
- * no activation) and the per-iteration convolutions only read the channels that change (round 4; unimatch_amd/refine_nhwc.py). */
+ * no activation) and the per-iteration convolutions only read the channels that change (round 4; unimatch_amd/refine_nhwc.py).
+ * gate 2 (v211): `z_out`, when non-null, receives the NEW hidden state (fp32 [rows][z_out_ld >= channels]) and `hidden` is only read --
+ * the loop's first q convolution reads net0 and writes the working state, so net0 is never copied (null: `hidden` updated in place). */
 int um_conv2d_gru_add_fwd(int gate, const void* a_planes, int a_ld, int a_coff, long a_rows, const void* w_planes, const float* bias,
                           const float* addend, int addend_ld, float* hidden, const float* z, int z_ld, float* z_out, int z_out_ld,
                           void* out_planes, int outp_ld, int outp_coff, long outp_rows, int batch, int hi, int wi, int cin,

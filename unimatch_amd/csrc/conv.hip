@@ -55,6 +55,8 @@ struct ConvArgs {
     int gate, gate_c, gate_zld;
     float* gate_h;
     const float* gate_z;
+    float* gate_hout;             // gate 2: where the new hidden state goes (gate_h itself: in place), row stride gate_hout_ld
+    int gate_hout_ld;
     float* stats;                 // optional [M / 128][3][Cout]: per 128-pixel tile (mean, 0, sum of squared deviations)
     // optional per-pixel addend, fp32 [M][addend_ld]: added to the scaled accumulator (+ bias) BEFORE the activation.  A convolution is
     // linear in its input channels, so the contribution of input channels that do not change between calls (the refinement loop's
@@ -115,6 +117,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
     float* hbase = gate ? a.gate_h + rowbase * a.gate_c : nullptr;
     const float* zbase = gate == 2 ? a.gate_z + rowbase * a.gate_zld : nullptr;
     const float* abase = a.addend ? a.addend + rowbase * a.addend_ld : nullptr;
+    float* hobase = gate == 2 ? a.gate_hout + rowbase * a.gate_hout_ld : nullptr;
     f32x4 ad[NSIDE][BATCH], gz[NSIDE][BATCH], gh[NSIDE][BATCH];
     auto preload = [&](int b, int slot) {                         // both compile-time constants once the callers' loops are unrolled
         if (!abase && !gate) return;
@@ -277,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue_pass(const ConvArgs& a, f32x16 (&a
                     } else if (GATE == 2) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) d[i] = (1.0f - gz[slot][j][i]) * gh[slot][j][i] + gz[slot][j][i] * d[i];
-                        *reinterpret_cast<f32x4*>(hbase + (unsigned)(r * a.gate_c + col)) = d;
+                        *reinterpret_cast<f32x4*>(hobase + (unsigned)(r * a.gate_hout_ld + col)) = d;
                     }
                     // streaming stores: the tile is next touched by another kernel; as ordinary stores these lines evicted the
                     // activation rows the neighbouring workgroups are about to re-read (+1.5 % end to end, same-box ABAB)
@@ -944,7 +947,12 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
                        float* out, int out_ld, int out_coff, void* out_planes, int outp_ld, int outp_coff, long outp_rows,
                        float* stats_out, int batch, int hi, int wi, int cin, int cout, int kh, int kw, int stride,
                        int pad_h, int pad_w, int act, int wshift, int mode, void* stream_, int gate, float* gate_h,
-                       const float* gate_z, int gate_zld, const float* addend = nullptr, int addend_ld = 0) {
+                       const float* gate_z, int gate_zld, const float* addend = nullptr, int addend_ld = 0, float* gate_hout = nullptr,
+                       int gate_hout_ld = 0) {
+    if (gate_hout && (gate != 2 || gate_hout_ld < cout || gate_hout_ld % 4 != 0 || ((unsigned long)gate_hout & 15) != 0)) {
+        um_set_error("um_conv2d: a separate new-state tensor goes with gate 2 only: 16-byte aligned fp32 [M][ld >= channels, ld %% 4 == 0]");
+        return -1;
+    }
     if (addend && (addend_ld < cout || addend_ld % 4 != 0 || ((unsigned long)addend & 15) != 0 || stats_out)) {
         um_set_error("um_conv2d: the addend must be 16-byte aligned fp32 [M][ld >= cout, ld %% 4 == 0] (and excludes fused statistics)");
         return -1;
@@ -1018,6 +1026,8 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     a.gate_h = gate_h;
     a.gate_z = gate_z;
     a.gate_zld = gate_zld;
+    a.gate_hout = gate_hout ? gate_hout : gate_h;
+    a.gate_hout_ld = gate_hout ? gate_hout_ld : a.gate_c;
     a.out_scale = ldexpf(1.f, -wshift);
     a.xcd = conv_xcd_enabled();
     hipError_t e;
@@ -1079,9 +1089,11 @@ extern "C" int um_conv2d_gru_add_fwd(int gate, const void* a_planes, int a_ld, i
         return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, z_out, z_out_ld, 0, out_planes, outp_ld, outp_coff,
                            outp_rows, nullptr, batch, hi, wi, cin, 2 * channels, kh, kw, 1, pad_h, pad_w, 2, wshift, mode, stream_,
                            1, hidden, nullptr, 0, addend, addend_ld);
+    // gate 2: z_out, when given, receives the new hidden state and `hidden` is only read (the refinement loop restarts from the same
+    // net0 in every iteration, unimatch.py:322-331: no copy of it per iteration)
     return conv2d_impl(a_planes, a_ld, a_coff, a_rows, w_planes, bias, nullptr, 0, 0, out_planes, outp_ld, outp_coff, outp_rows,
                        nullptr, batch, hi, wi, cin, channels, kh, kw, 1, pad_h, pad_w, 3, wshift, mode, stream_, 2, hidden, z, z_ld,
-                       addend, addend_ld);
+                       addend, addend_ld, z_out, z_out_ld);
 }
 
 extern "C" int um_conv2d_fwd(const void* a_planes, const void* w_planes, const float* bias, float* out, float* stats_out,

@@ -601,11 +601,12 @@ class HipOps:
             {'flops': 2.0 * b * ho * wo * cout * kh * kw * cin})
         _abi.check(code, 'um_conv2d_ex')
 
-    def conv_gru(self, gate, src, geom, wb, ksize, pad, hidden, outp, z=None, z_out=None, addend=None):
+    def conv_gru(self, gate, src, geom, wb, ksize, pad, hidden, outp, z=None, z_out=None, addend=None, hidden_out=None):
         """``um_conv2d_gru_fwd``: gate 1 = (z | r) convolution -> ``z_out`` fp32 and ``r * hidden`` planes; gate 2 = q
         convolution -> ``hidden`` updated in place and written as planes.  ``src`` / ``wb`` / ``outp`` as :meth:`conv_ex`.
         ``addend``: fp32 ``[rows, cout]`` added before the gate's activation (``um_conv2d_gru_add_fwd``: the iteration-invariant
-        input channels' share of the convolution, computed once per scale)."""
+        input channels' share of the convolution, computed once per scale).  ``hidden_out`` (gate 2 with an addend): the new state goes
+        there and ``hidden`` is only read."""
         buf, a_ld, a_coff, cin = src
         b, h, w = geom
         (wp, cout, wcin, kh, kw), bias = wb
@@ -614,6 +615,10 @@ class HipOps:
             raise ValueError('conv_gru: weight / hidden shapes do not match')
         p_t, p_ld, p_coff = outp
         zt = z if gate == 2 else None
+        if hidden_out is not None:
+            if gate != 2 or addend is None or hidden_out.shape != hidden.shape or hidden_out.dtype != torch.float32 or not hidden_out.is_contiguous():
+                raise ValueError('conv_gru: hidden_out goes with gate 2 and an addend, contiguous fp32 of the hidden state\'s shape')
+            z_out = hidden_out
         if addend is not None:
             if not (addend.dtype == torch.float32 and addend.is_contiguous() and addend.dim() == 2 and addend.shape[1] == cout
                     and addend.shape[0] == geom[0] * geom[1] * geom[2]):

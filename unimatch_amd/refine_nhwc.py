@@ -142,15 +142,20 @@ class NhwcUpdateBlock:
         ops.conv_ex((self.CF, 256, 0, 256), g, W['mo'], (3, 3), 1, (1, 1), 1, outp=(self.G, 512, 256))
         ops.nhwc_gate(0, flow.permute(0, 2, 3, 1).reshape(rows, fd).contiguous(), self.G, 512, 384 - fd, rows, fd)
         # SepConvGRU (reg_refine.py:55-76); the hidden state restarts from net0 every iteration (unimatch.py:322-331)
-        self.H.copy_(self.net0)
-        ops.nhwc_gate(0, self.H, self.G, 512, self.c_h, rows, 128)
+        if not self.hoist:
+            self.H.copy_(self.net0)
+            ops.nhwc_gate(0, self.H, self.G, 512, self.c_h, rows, 128)
         for tag, ks, pad in (('1', (1, 5), (0, 2)), ('2', (5, 1), (2, 0))):
             # gate arithmetic in the convolutions' epilogues: (z | r) -> z (fp32) and r * h (planes); q -> h updated in place
             if self.hoist:      # only the columns that change; the invariant share comes in as the epilogue's addend
-                zsrc = (self.G, 512, 256, 128) if tag == '1' else (self.G, 512, 128, 256)
-                ops.conv_gru(1, zsrc, g, W['zr' + tag + 'v'], ks, pad, self.H, (self.G, 512, 384), z_out=self.ZR, addend=self.P['zr' + tag])
-                ops.conv_gru(2, (self.G, 512, 256, 256), g, W['q' + tag + 'v'], ks, pad, self.H, (self.G, 512, 128), z=self.ZR,
-                             addend=self.P['q' + tag])
+                # pass 1 reads net0 itself (its planes are not read at all: h's share of z | r sits in the addend) and the first q
+                # convolution writes the working state H and its planes: no copy of net0, no plane scatter per iteration (round 5)
+                first = tag == '1'
+                zsrc = (self.G, 512, 256, 128) if first else (self.G, 512, 128, 256)
+                ops.conv_gru(1, zsrc, g, W['zr' + tag + 'v'], ks, pad, self.net0 if first else self.H, (self.G, 512, 384), z_out=self.ZR,
+                             addend=self.P['zr' + tag])
+                ops.conv_gru(2, (self.G, 512, 256, 256), g, W['q' + tag + 'v'], ks, pad, self.net0 if first else self.H, (self.G, 512, 128),
+                             z=self.ZR, addend=self.P['q' + tag], hidden_out=self.H if first else None)
             else:
                 ops.conv_gru(1, (self.G, 512, 0, 384), g, W['zr' + tag], ks, pad, self.H, (self.G, 512, 384), z_out=self.ZR)
                 ops.conv_gru(2, (self.G, 512, 128, 384), g, W['q' + tag], ks, pad, self.H, (self.G, 512, 0), z=self.ZR)
