@@ -930,7 +930,11 @@ static ConvKind conv_pick(int hi, int wi, int ho, int wo, int cout, int kh, int 
     const bool rows3 = same && kw == 3 && pad_w == 1, rows5 = same && kw == 5 && pad_w == 2 && nt == 4;
     // 3x3: the 2-D patch kernel when at least 3/4 of the 8 x 32 tiles' area is image
     const long tiled = (long)((ho + 7) / 8 * 8) * ((wo + 31) / 32 * 32);
-    if (rows3 && kh == 3 && pad_h == 1 && 4L * ho * wo >= 3 * tiled && strchr(patch_nts, '0' + nt) != nullptr) return CONV_PATCH;
+    if (rows3 && kh == 3 && pad_h == 1 && 4L * ho * wo >= 3 * tiled && strchr(patch_nts, '0' + nt) != nullptr) {
+        // heads with a handful of outputs (the flow head's second convolution: 256 -> 2): a 32-wide tile, half the products of a 64-wide one
+        if (cout <= 32) *nt_out = 1;
+        return CONV_PATCH;
+    }
     return rows3 || rows5 ? CONV_ROWS : CONV_GENERIC;
 }
 
@@ -1034,7 +1038,9 @@ static int conv2d_impl(const void* a_planes, int a_ld, int a_coff, long a_rows, 
     int nt;
     const ConvKind kind = conv_pick(hi, wi, ho, wo, cout, kh, kw, stride, pad_h, pad_w, &nt);
     hipStream_t st = (hipStream_t)stream_;
-    if (kind == CONV_PATCH) e = nt == 2 ? launch_conv_patch<2>(a, mode, st) : nt == 3 ? launch_conv_patch<3>(a, mode, st) : launch_conv_patch<4>(a, mode, st);
+    if (kind == CONV_PATCH)
+        e = nt == 1 ? launch_conv_patch<1>(a, mode, st) : nt == 2 ? launch_conv_patch<2>(a, mode, st) : nt == 3 ? launch_conv_patch<3>(a, mode, st)
+                                                                                                          : launch_conv_patch<4>(a, mode, st);
     else if (kind == CONV_ROWS && kw == 5) e = launch_conv_rows<4, 5, 2>(a, mode, st);
     else if (kind == CONV_ROWS) e = nt == 2 ? launch_conv_rows<2, 3, 2>(a, mode, st) : nt == 3 ? launch_conv_rows<3, 3, 2>(a, mode, st) : launch_conv_rows<4, 3, 2>(a, mode, st);
     else e = nt == 2 ? launch_conv<2>(a, mode, st) : nt == 3 ? launch_conv<3>(a, mode, st) : launch_conv<4>(a, mode, st);
