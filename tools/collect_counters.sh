@@ -12,7 +12,7 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$R"
-KERNELS="window_attn ffn_kernel gsv4_kernel kv4_kernel"
+KERNELS="${KERNELS:-window_attn ffn_kernel gsv4_kernel kv4_kernel}"
 pass() {   # pass <name> <counters...>
     local name=$1; shift
     (cd /tmp && timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/${TAG}_$name -o p -- \
