@@ -1327,6 +1327,36 @@ def test_cost_volume_dispatch_is_a_pure_function_of_the_call():
     lib.um_census_enable(0)
 
 
+def test_cost_volume_target_order_at_full_size():
+    """The target-ordered cost volume at config 3's refinement geometry (4 x 128 x 240: 32 sorting workgroups, more (image, cell) groups
+    than a workgroup has threads, spans that end inside an image): against the natural-tile walk of the same call (flags bit 1; that
+    path is pinned to the oracle at small sizes above) to rounding, bitwise reproducible, exact zeros where nothing is sampled, and
+    bitwise independent of what shares a pixel's group (the other images' flow changed)."""
+    o = HipOps('exact')
+    b, h, w = 4, 128, 240
+    g = torch.Generator().manual_seed(160)
+    t0 = (torch.randn(b, h * w, C, generator=g) * 0.5).to(DEV)
+    t1 = (torch.randn(b, h * w, C, generator=g) * 0.5).to(DEV)
+    flow = (torch.randn(b, 2, h, w, generator=g) * 30.0).to(DEV)
+    flow[1, 0, :, : w // 3] += 900.0                                          # a third of image 1 samples nothing
+    flow[2] = 0.7                                                            # image 2 is coherent (its pixels still go through the sort)
+    got = o.local_corr_with_flow(t0, t1, flow, h, w, 4)
+    again = o.local_corr_with_flow(t0, t1, flow, h, w, 4)
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    o.k4_flags = 2
+    try:
+        natural = o.local_corr_with_flow(t0, t1, flow, h, w, 4)
+    finally:
+        o.k4_flags = 0
+    scale = max(1.0, natural.abs().max().item())
+    assert (got - natural).abs().max().item() < 3e-6 * scale
+    assert torch.equal(got[1, :, :, : w // 3], torch.zeros_like(got[1, :, :, : w // 3]))
+    other = flow.clone()
+    other[0] = torch.randn(2, h, w, generator=g).to(DEV) * 30.0               # different groups everywhere in image 0 ...
+    got2 = o.local_corr_with_flow(t0, t1, other, h, w, 4)
+    assert torch.equal(got2[1:], got[1:])                                    # ... the other images do not notice
+
+
 def _refine_model(name, gain=0.02):
     ck, fk = CONFIGS[name]
     model = UniMatch(**ck).eval()
