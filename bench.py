@@ -144,6 +144,18 @@ def pmc_mfma_busy(kernel_key, files):
         return None, 'no PMC pass on record for this launch shape'
 
 
+def pmc_other_units(kernel_key, files):
+    """LDS-array and VALU busy fractions of the kernel from the same tracked PMC passes (SQ_LDS_IDX_ACTIVE / (256 CUs x cycles);
+    4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles), MFMA issue included): what the matrix pipe is NOT waiting for.  Source-stamped."""
+    try:
+        rec = json.load(open(PMC_FILE))[kernel_key]
+        if rec.get('source_stamp') != source_stamp(files):
+            return None, None
+        return rec.get('lds_busy'), rec.get('valu_busy')
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, precision, pmc_ok, bound='mfma'):
     """One roofline object: `achieved` = algorithmic FLOPs of the kernel's launches in a step / the summed hipEvent
     duration of those launches (breakdown pass).  With one launch shape per step this is per launch; with several (config 4: two
@@ -157,12 +169,13 @@ def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, 
     ach = flops_per_step / dur
     traffic, note = pmc_traffic(key, files) if pmc_ok else (None, 'no PMC pass for this workload / batch')
     busy, busy_note = pmc_mfma_busy(key, files) if pmc_ok else (None, 'no PMC pass for this workload / batch')
+    lds_busy, valu_busy = pmc_other_units(key, files) if pmc_ok else (None, None)
     return {'kernel': name, 'bound': bound, 'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12,
             'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic,
             'traffic_unit': 'MB per launch', 'traffic_source': note, 'launches': n,
             'avg_launch_ms': round(ms / n, 4), 'algorithmic_gflop_per_launch': round(flops_per_step / launches_per_step / 1e9, 2),
             'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
-            'mfma_busy': busy, 'mfma_busy_source': busy_note,
+            'mfma_busy': busy, 'mfma_busy_source': busy_note, 'lds_busy': lds_busy, 'valu_busy': valu_busy,
             'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
             'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4),
             'duration_source': 'hipEvent pairs on the launch stream (um_timing_*), breakdown pass after the event-free headline region'}
