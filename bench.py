@@ -18,6 +18,10 @@ resident in HBM; with N GPUs every rank runs its own batch (weak scaling, no dat
 predictions are all-gathered over RCCL (``um_allgather_preds`` of the library's C ABI = ncclAllGather, on a side stream
 so that the gather of step k overlaps step k+1) -- K timed steps contain K complete all-gathers.
 Rank 0 prints ONE JSON line; ``value`` is whole-job image-pairs/s in EXACT mode (the parity mode).
+Round 5: by default the step computes its 8 pairs as TWO concurrent forwards of 4 pairs on two HIP streams
+(``unimatch_amd.streams.ConcurrentUniMatch``, ``--streams 2``): the samples of a batch are independent, and the halves fill one
+another's launch tails (the attention launch alone leaves a half-empty last round); every half is bitwise the plain forward of its
+samples.  ``--streams 1`` = one forward of 8; the line carries that figure as ``serial`` either way.
 
 The headline region is EVENT-FREE (round 4): ``value`` / ``ms_per_step`` come from K steps bracketed by barrier + synchronize with
 no per-kernel event inside.  Directly after it a BREAKDOWN pass runs the same K steps twice with the library's per-kernel hipEvents
@@ -78,6 +82,10 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (cfg2, default 8) / global batch (cfg4, default 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='cfg2: the batch as this many concurrent forwards on separate HIP streams (unimatch_amd.streams: the halves fill '
+                         'one another\'s launch tails; 1 = one forward of the whole batch).  The roofline / breakdown pass always runs one '
+                         'forward with its launches serialised, and the line carries the one-forward throughput as `serial`')
     ap.add_argument('--graph', action='store_true',
                     help='replay the HIP graph of the forward (unimatch_amd.graph) in the timed steps instead of launching eagerly '
                          '(measured on MI355X at config 2: 817.5 / 817.0 pairs/s against 818.6 / 819.1 eager -- the step is GPU-bound, '
@@ -307,16 +315,25 @@ def main():
 
     step_ms = []
 
-    def timed(precision, steps, warmup):
+    concurrent = {}
+
+    def timed(precision, steps, warmup, streams=None):
         """The headline region: K steps, barrier + synchronize on both sides, no per-kernel event inside."""
         model.set_precision(precision)
         launch['fwd'], launch['mode'] = model, 'eager'
+        streams = args.streams if streams is None else streams
+        if streams > 1 and not args.graph:
+            from unimatch_amd.streams import ConcurrentUniMatch
+            if streams not in concurrent:
+                concurrent[streams] = ConcurrentUniMatch(model, parts=streams)
+            launch['fwd'] = concurrent[streams]
+            launch['mode'] = f'eager, {min(streams, b)} concurrent forwards of {b // min(streams, b)} pairs on {min(streams, b)} HIP streams'
         if args.graph:
             from unimatch_amd.graph import GraphedUniMatch
             launch['fwd'], launch['mode'] = GraphedUniMatch(model), 'hip_graph_replay'      # captured by the first warm-up step
-        for _ in range(max(warmup, 1)):
+        for _ in range(max(warmup, 2)):                              # (the stream wrapper's first call of a geometry is sequential)
             pred = step()
-        if launch['mode'] != 'eager' and any(v is False for v in launch['fwd']._graphs.values()):
+        if launch['mode'].startswith('hip_graph') and any(v is False for v in launch['fwd']._graphs.values()):
             launch['fwd'], launch['mode'] = model, 'eager (HIP graph capture failed)'
         finish_gather()
         torch.cuda.synchronize()
@@ -389,6 +406,12 @@ def main():
     elapsed, pred, launch_mode = timed(args.precision, args.steps, args.warmup)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     spread_ms = (step_ms[0], step_ms[-1])
+    serial = None
+    if 'concurrent' in launch_mode:                                # the same K steps as ONE forward per step (what the breakdown pass times)
+        s_el, _, _ = timed(args.precision, args.steps, 2, streams=1)
+        serial = {'value': round(world * b * args.steps / s_el, 3), 'unit': 'pairs/s', 'ms_per_step': round(s_el / args.steps * 1e3, 3),
+                  'note': 'one forward of the whole per-GPU batch per step, launches serialised on one stream: the mode the roofline '
+                          'durations, hot_path_ms_per_step and encoder_ms_per_step of this line are measured in'}
     hot_t, enc_t, enc_wall_ms = breakdown(args.steps)
     other = 'fast' if args.precision == 'exact' else 'exact'
     extra = None
@@ -558,6 +581,7 @@ def main():
         'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,
         'config': {'workload': workload,
                    'per_gpu_batch': b, 'global_batch': gb, 'precision': args.precision, 'launch_mode': launch_mode,
+                   'streams': (min(args.streams, b) if 'concurrent' in launch_mode else 1),
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; every '
                                      'GEMM / convolution of the forward runs on the library\'s own split-fp16 MFMA kernels '
                                      '(no MIOpen, hipBLASLt or rocBLAS kernel in the forward)',
@@ -571,14 +595,18 @@ def main():
         'hot_path_ms_per_step': hot_ms, 'encoder_ms_per_step': enc_ms,
         'encoder_wall_ms_per_step': round(enc_wall_ms, 3),
         'hot_path_kernels_ms_per_step': hot_per, 'encoder_kernels_ms_per_step': enc_per,
-        'untimed_ms_per_step': round(median_ms - hot_ms - enc_ms, 3),
+        'untimed_ms_per_step': round((serial['ms_per_step'] if serial else median_ms) - hot_ms - enc_ms, 3),
+        'serial': serial,
         'hot_path_pairs_per_sec': round((b if not cfg4 else b) / (hot_ms * 1e-3), 1) if hot_ms else None,
         'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps), eager launches (--graph replays '
-                       'the forward as a HIP graph: no gain, the step is GPU-bound; config.launch_mode).  roofline durations, '
+                       'the forward as a HIP graph: no gain, the step is GPU-bound; config.launch_mode).  With --streams N > 1 (default 2) a '
+                       'step computes the per-GPU batch as N concurrent forwards on N HIP streams (unimatch_amd.streams: the parts fill one '
+                       'another\'s launch tails; every part is bitwise the plain forward of its samples) and `serial` is the same K steps as '
+                       'one forward per step.  roofline durations (kernels alone on the GPU, one forward per step), '
                        'hot_path_ms_per_step (kernel-duration sum of everything outside the CNN encoder = SURVEY 8\'s path) and '
                        'encoder_ms_per_step (the encoder\'s launches, SURVEY 2 #8, out of scope) come from a separate breakdown '
                        'pass of the same K steps with per-kernel hipEvents on the launch stream; hot_path_pairs_per_sec = this '
-                       'rank\'s pairs / hot_path_ms_per_step; untimed_ms_per_step = median step - both sums (ATen element-wise ops such '
+                       'rank\'s pairs / hot_path_ms_per_step; untimed_ms_per_step = (serial, else median) step - both sums (ATen element-wise ops such '
                        'as the position add, a few sub-10-us glue kernels, launch gaps)',
         'fast' if other == 'fast' else 'exact': fast_obj,
         'cpu_baseline': cpu, 'rocm_eager_baseline': eager, 'epe': epe or None,

@@ -16,7 +16,7 @@ from oracle import hotpath as hp
 from oracle import model as om
 from unimatch_amd import UniMatch
 from unimatch_amd.ops import HipOps
-from unimatch_amd.synth import CONFIGS, synth_camera, synth_images, synth_state_dict
+from unimatch_amd.synth import CONDITIONED, CONFIGS, synth_camera, synth_images, synth_state_dict
 
 pytestmark = pytest.mark.gpu
 C = 128
@@ -1355,6 +1355,41 @@ def test_cost_volume_target_order_at_full_size():
     other[0] = torch.randn(2, h, w, generator=g).to(DEV) * 30.0               # different groups everywhere in image 0 ...
     got2 = o.local_corr_with_flow(t0, t1, other, h, w, 4)
     assert torch.equal(got2[1:], got[1:])                                    # ... the other images do not notice
+
+
+def test_concurrent_forwards_on_two_streams():
+    """``ConcurrentUniMatch``: a batch as two forwards on two HIP streams.  Every part is bitwise the plain forward of its samples; against
+    the one-forward result the difference stays at the fp32 noise floor (launch-size dependent summation orders only); repeated calls are
+    bitwise equal (no race on the caches the first, sequential, call builds); the refinement path (plane buffers per stream) included."""
+    from unimatch_amd.streams import ConcurrentUniMatch
+    for name, b, hh, ww in (('gmflow_s1', 4, 128, 192), ('gmflow_s2_rr6', 3, 128, 192), ('gmdepth_s1', 4, 96, 128)):
+        ck, fk = CONFIGS[name]
+        model = UniMatch(**ck).eval()
+        model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, **CONDITIONED))
+        model = model.to(DEV)
+        i0, i1 = synth_images(b, hh, ww, seed=31, kind='shift', normalized=(fk['task'] != 'flow'))
+        i0, i1 = i0.to(DEV), i1.to(DEV)
+        kw = dict(fk)
+        if fk['task'] == 'depth':
+            k, pose = synth_camera(b, hh, ww)
+            kw.update(intrinsics=k.to(DEV), pose=pose.to(DEV))
+        whole = model(i0, i1, **kw)['flow_preds'][0]
+        wrapped = ConcurrentUniMatch(model, parts=2)
+        first = wrapped(i0, i1, **kw)['flow_preds'][0]                # sequential: builds the caches
+        runs = [wrapped(i0, i1, **kw)['flow_preds'][0] for _ in range(4)]      # concurrent
+        torch.cuda.synchronize()
+        assert all(torch.equal(r, first) for r in runs)
+        lo = 0
+        for r, n in enumerate((b - b // 2, b // 2)):
+            pk = dict(kw)
+            for key in ('intrinsics', 'pose'):
+                if pk.get(key) is not None:
+                    pk[key] = pk[key][lo:lo + n].contiguous()
+            alone = model(i0[lo:lo + n].contiguous(), i1[lo:lo + n].contiguous(), **pk)['flow_preds'][0]
+            assert torch.equal(first[lo:lo + n], alone)
+            lo += n
+        assert torch.isfinite(first).all()
+        assert (first - whole).abs().max().item() < 1e-3 * max(1.0, whole.abs().max().item())
 
 
 def _refine_model(name, gain=0.02):

@@ -306,3 +306,25 @@ def test_kv4_weight_packing_matches_the_header():
     # every output row of the four projections appears exactly once
     rows = torch.cat([wc[:, :128], wc[:, 128:]], 0)
     assert torch.equal(rows.sort(0).values, w4.sort(0).values)
+
+
+def test_concurrent_wrapper_splits_and_reassembles_a_batch():
+    """``ConcurrentUniMatch`` (one batch as several forwards; concurrent on HIP streams, one after the other on the CPU): uneven parts,
+    the [forward; backward] layout of bidirectional outputs and per-sample camera arguments come back in the order of the one-forward
+    result (the samples of a batch are independent: same result to fp32 re-association)."""
+    from unimatch_amd.streams import ConcurrentUniMatch
+    model, sd, i0, i1, kw, ck = build('gmflow_s1', batch=3)
+    model.bind_ops(OracleOps())
+    whole = model(i0, i1, pred_bidir_flow=True, **kw)['flow_preds'][0]
+    for parts in (2, 3, 5):
+        wrapped = ConcurrentUniMatch(model, parts=parts)
+        for _ in range(2):                                           # second call: the geometry is known (same path on the CPU)
+            got = wrapped(i0, i1, pred_bidir_flow=True, **kw)['flow_preds'][0]
+            assert got.shape == whole.shape == (6, 2, 64, 96)
+            assert (got - whole).abs().max().item() < 1e-4
+    model, sd, i0, i1, kw, ck = build('gmdepth_s1_rr1', batch=2)
+    model.bind_ops(OracleOps())
+    whole = model(i0, i1, **kw)['flow_preds'][0]
+    got = ConcurrentUniMatch(model, parts=2)(i0, i1, **kw)['flow_preds'][0]
+    assert got.shape == whole.shape and (got - whole).abs().max().item() < 1e-4 * whole.abs().max().item()
+    assert ConcurrentUniMatch(model, parts=1)(i0, i1, **kw)['flow_preds'][0].shape == whole.shape

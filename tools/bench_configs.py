@@ -24,6 +24,7 @@ WEIGHTS = ARGV[ARGV.index('--weights') + 1] if '--weights' in ARGV else 'damped'
 WKW = CONDITIONED if WEIGHTS == 'conditioned' else dict(refine_gain=0.02)
 K4_FLAGS = int(ARGV[ARGV.index('--k4-flags') + 1]) if '--k4-flags' in ARGV else 0     # 2: natural tiles only (no target ordering), 1: per-pixel path
 REPEAT = int(ARGV[ARGV.index('--repeat') + 1]) if '--repeat' in ARGV else 1
+STREAMS = int(ARGV[ARGV.index('--streams') + 1]) if '--streams' in ARGV else 1       # > 1: the batch as concurrent forwards (unimatch_amd.streams)
 import ctypes
 from unimatch_amd import _abi
 for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
@@ -34,6 +35,10 @@ for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
     model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, **WKW))
     model = model.cuda()
     model.ops.k4_flags = K4_FLAGS
+    plain = model
+    if STREAMS > 1:
+        from unimatch_amd.streams import ConcurrentUniMatch
+        model = ConcurrentUniMatch(plain, parts=STREAMS)
     i0, i1 = synth_images(b, hh, ww, seed=3, kind='shift', normalized=(fk['task'] != 'flow'))
     kw = dict(fk)
     if fk['task'] == 'depth':
@@ -51,11 +56,11 @@ for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
         # the cost volume's launches of one more forward, timed by the library's own events (UM_K_COST_VOLUME = 4)
         lib.um_timing_enable(1 << 4)
-        model(i0, i1, **kw)
+        plain(i0, i1, **kw)
         torch.cuda.synchronize()
         ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
         lib.um_timing_collect(4, ctypes.byref(ms), ctypes.byref(cnt))
         lib.um_timing_enable(0)
         k4 = f'  K4 {cnt.value} x {ms.value / max(cnt.value, 1):.3f} ms' if cnt.value else ''
         print(f'{label:58s} out {tuple(out.shape)} finite={bool(torch.isfinite(out).all())}  {dt*1e3:8.2f} ms/step  {b/dt:8.1f} pairs/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB{k4}', flush=True)
-    del model, out; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    del model, plain, out; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()

@@ -16,7 +16,7 @@ KERNELS="${KERNELS:-window_attn ffn_kernel gsv4_kernel kv4_kernel}"
 pass() {   # pass <name> <counters...>
     local name=$1; shift
     (cd /tmp && timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/${TAG}_$name -o p -- \
-        python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast > "$OUT/${TAG}_pmc_$name.log" 2>&1 < /dev/null)
+        python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-fast --streams 1 > "$OUT/${TAG}_pmc_$name.log" 2>&1 < /dev/null)
     local f
     f=$(find /tmp/${TAG}_$name -name '*counter_collection.csv' | head -1)
     if [ -n "$f" ]; then python tools/pmc_summary.py "$f" $KERNELS > "$OUT/${TAG}_pmc_$name.json"; else echo "pass $name: no counter file"; tail -5 "$OUT/${TAG}_pmc_$name.log"; fi

@@ -5,6 +5,7 @@ matching, propagation and cost-volume layers run on hand-written HIP kernels beh
 ``include/unimatch_hip.h``.
 """
 from .model import UniMatch  # noqa: F401
+from .streams import ConcurrentUniMatch  # noqa: F401
 
-__all__ = ['UniMatch']
+__all__ = ['UniMatch', 'ConcurrentUniMatch']
 __version__ = '0.1.0'

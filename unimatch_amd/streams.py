@@ -1,0 +1,86 @@
+"""One batch as several concurrent forwards on separate HIP streams of ONE GPU.
+
+The samples of a batch are independent (InstanceNorm is per sample, every matching layer is per pair: /root/reference/unimatch/unimatch.py
+:113-367 has no cross-sample operation), and the hot path's launches do not tile the chip evenly: the attention launch of config 2 is 768
+workgroups on 512 resident slots (a half-empty last round at 37 % matrix-pipe busy), the FFN runs three synchronised rounds
+whose prologues / epilogues overlap with nothing.  Two forwards of half the batch on two streams fill one another's tails: while one half's
+launch drains, the other half's next launch starts.  Measured at config 2 (8 x 512x768): 9.67 -> 9.17 ms per step on one box, 9.20 -> 8.92 on
+another (+3 ... +5 %); four forwards of two pairs LOSE (10.4 ms: launches of a quarter of the chip).  Default two parts.
+
+What it is not: a different computation.  Every part is a plain ``UniMatch.forward`` of its samples; results agree with the one-forward
+result to the summation order of the launch-size-dependent decompositions (stream-K split points of the global correlation), i.e. to the
+fp32 noise floor the parity tables are measured against, and are bitwise those of forwarding the part alone.
+"""
+import torch
+
+from .dist import shard_batch, shard_bounds
+
+
+class ConcurrentUniMatch(torch.nn.Module):
+    """``ConcurrentUniMatch(model, parts=2)(img0, img1, **kw)`` = ``model(img0, img1, **kw)`` computed as ``parts`` forwards of
+    contiguous sample ranges, each on its own stream, joined on the caller's stream.
+
+    The first forward of a geometry / argument set / parameter version runs the parts one after the other on the caller's stream:
+    that is the forward that builds the caches later forwards only read (weight planes, position tables, plane buffers are keyed per
+    stream where they are written per forward) -- concurrent first use would race on them."""
+
+    def __init__(self, model, parts=2):
+        super().__init__()
+        if parts < 1:
+            raise ValueError('parts must be >= 1')
+        self.model = model
+        self.parts = parts
+        self._streams = {}
+        self._seen = set()
+
+    def _key(self, img0, kw):
+        version = sum(p._version for p in self.model.parameters())
+        small = tuple(sorted((k, v if isinstance(v, (int, float, bool, str, type(None))) else
+                              tuple(v) if isinstance(v, (list, tuple)) else tuple(v.shape)) for k, v in kw.items()))
+        return (tuple(img0.shape), str(img0.device), small, version, torch.is_grad_enabled())
+
+    def forward(self, img0, img1, **kw):
+        batch = img0.shape[0]
+        n = min(self.parts, batch)
+        if n == 1:
+            return self.model(img0, img1, **kw)
+        bidir = 2 if (kw.get('pred_bidir_flow') or kw.get('pred_bidir_depth')) else 1
+
+        def part_inputs(r):
+            pk = dict(kw)
+            for key in ('intrinsics', 'pose'):
+                if pk.get(key) is not None:
+                    pk[key] = shard_batch(pk[key], r, n)
+            return shard_batch(img0, r, n), shard_batch(img1, r, n), pk
+
+        key = self._key(img0, kw)
+        concurrent = img0.is_cuda and key in self._seen
+        outs = []
+        if not concurrent:
+            for r in range(n):
+                a0, a1, pk = part_inputs(r)
+                outs.append(self.model(a0, a1, **pk)['flow_preds'])
+            self._seen.add(key)
+        else:
+            dev = img0.device
+            cur = torch.cuda.current_stream(dev)
+            streams = self._streams.setdefault(str(dev), [])
+            while len(streams) < n:
+                streams.append(torch.cuda.Stream(device=dev))
+            ins = [part_inputs(r) for r in range(n)]                # sliced on the caller's stream
+            for r in range(n):
+                s = streams[r]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    outs.append(self.model(ins[r][0], ins[r][1], **ins[r][2])['flow_preds'])
+            for r in range(n):
+                cur.wait_stream(streams[r])
+                for t in outs[r]:
+                    t.record_stream(cur)                            # allocated on the part's stream, consumed on the caller's
+        # every prediction of the list: [bidir * b_r, ...] per part -> [bidir * batch, ...] in the reference's [forward; backward] order
+        counts = [shard_bounds(batch, r, n)[1] - shard_bounds(batch, r, n)[0] for r in range(n)]
+        preds = []
+        for i in range(len(outs[0])):
+            pieces = [outs[r][i].reshape(bidir, counts[r], *outs[r][i].shape[1:]) for r in range(n)]
+            preds.append(torch.cat(pieces, 1).reshape(bidir * batch, *outs[0][i].shape[1:]))
+        return {'flow_preds': preds}
