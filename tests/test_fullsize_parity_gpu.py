@@ -78,3 +78,29 @@ def test_batch_and_single_sample_forwards_agree(legs):
     b8, _ = pf.gpu_case(2, 'conditioned', KIND, SEED)
     b1, _ = pf.gpu_case(2, 'conditioned', KIND, SEED, samples=(0, 1))
     assert pf.epe(b8[:1], b1) < 1e-4
+
+
+def test_the_benchs_concurrent_half_batches_are_the_measured_kernels(legs):
+    """bench.py's default step (round 5) computes config 2's 8 pairs as two concurrent forwards of 4 on two streams.  Both halves must
+    run the kernels the parity tables cover -- the tile instantiations of attention / FFN and gsv4, no small-launch split variant: 384
+    query tiles are more than the chip's split rule admits -- and the result must sit on the batch forward's (accumulation order of
+    the launch-size dependent decompositions only; conditioned weights: far below the 1e-3 px gate)."""
+    from unimatch_amd import ConcurrentUniMatch, UniMatch, _abi
+    ck, kw, i0, i1 = pf.case_inputs(2, KIND, SEED)
+    model = UniMatch(**ck).eval()
+    model.load_state_dict(pf.weights(ck, 'conditioned'))
+    model = model.cuda()
+    kw = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    i0, i1 = i0.cuda(), i1.cuda()
+    whole = model(i0, i1, **kw)['flow_preds'][0]
+    wrapped = ConcurrentUniMatch(model, parts=2)
+    wrapped(i0, i1, **kw)                                             # first call: sequential, builds the caches
+    lib = _abi.load()
+    lib.um_census_enable(1)
+    got = wrapped(i0, i1, **kw)['flow_preds'][0]                      # concurrent
+    torch.cuda.synchronize()
+    census = {k: v for k, v in _abi.census(lib).items() if v}
+    lib.um_census_enable(0)
+    assert not pf.check_census(2, 4, census), census
+    assert census['wattn_tile'] == 24 and census['ffn_tile'] == 12 and census['gsv4'] == 4, census
+    assert pf.epe(got.cpu(), whole.cpu()) < 1e-4
