@@ -10,6 +10,7 @@ from unimatch_amd.synth import CONFIGS, synth_images, synth_state_dict
 ARGV = sys.argv[1:]
 STEPS = int(ARGV[ARGV.index('--steps') + 1]) if '--steps' in ARGV else 20
 PARTS = int(ARGV[ARGV.index('--parts') + 1]) if '--parts' in ARGV else 2
+STAGGER = '--stagger' in ARGV        # part k + 1 starts when part k has left its CNN encoder (Transformer of one beside the encoder of the next)
 ck, fk = CONFIGS['gmflow_s1']
 model = UniMatch(**ck).eval()
 model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}))
@@ -25,11 +26,27 @@ def whole():
     return model(i0, i1, **fk)['flow_preds'][0]
 
 
+enc_done = {}
+
+
+def _after_encoder(_m, _a, _o):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    enc_done['ev'] = ev
+
+
+if STAGGER:
+    model.backbone.register_forward_hook(_after_encoder)
+
+
 def split():
     outs = []
     cur = torch.cuda.current_stream()
+    enc_done.pop('ev', None)
     for s, (a0, a1) in zip(streams, chunks):
         s.wait_stream(cur)
+        if STAGGER and 'ev' in enc_done:
+            s.wait_event(enc_done['ev'])
         with torch.cuda.stream(s):
             outs.append(model(a0, a1, **fk)['flow_preds'][0])
     for s in streams:
