@@ -112,7 +112,7 @@ int um_range_flags(unsigned* flags_out, int reset);
 #define UM_V_CONV_PATCH 10    /* conv_patch_kernel (3x3 stride 1, 2-D halo patch)                                       */
 #define UM_V_CONV_ROWS 11     /* conv_rows_kernel (row window shared by the horizontal taps)                            */
 #define UM_V_CONV_GENERIC 12  /* conv_kernel (tap-by-tap implicit GEMM)                                                 */
-#define UM_V_WATTN_W8 13      /* window_attn8_kernel: one 8-wave workgroup per query tile, keys halved inside (big launches) */
+#define UM_V_WATTN_W8 13      /* reserved: an 8-wave attention variant measured and dropped in round 5 (never counted) */
 #define UM_V_COUNT 14
 int um_census_enable(int on);
 long um_census_count(int variant);

@@ -847,648 +847,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
-#ifndef UM_WATTN_W8
-#define UM_WATTN_W8 0      // round 5: built, parity-green, measured slower than window_attn_kernel (profiles/r05_attention_experiments.txt): diagnostic builds only
-#endif
-#if UM_WATTN_W8
-// =====================================================================================================================
-// window_attn8_kernel (round 5): the layer kernel (query projection + attention + merge + LayerNorm) for BIG launches as ONE
-// 8-wave workgroup per CU and query tile.  What the counters of round 5 say about window_attn_kernel at config 2
-// (profiles/r05_pmc_bounds.json): the LDS array is busy 18 % of the CU cycles, the VALU 34 %, the matrix pipe 50 %, no bank
-// conflict -- nothing is saturated; the two co-resident waves of a SIMD (of two INDEPENDENT workgroups) simply spend their VALU
-// phases (bias / softmax / operand split: ~1300 of ~4600 cycles per tile) and their MFMA phases beside each other as chance
-// has it, and 768 tiles on 512 resident slots leave the last third of the launch with one wave per SIMD.
-//
-// Here the two waves of a SIMD belong to the SAME workgroup and work on the SAME 128 queries: wave group A (waves 0-3) walks
-// the first half of the window's key tiles, group B (waves 4-7; wave w and w + 4 share a SIMD) the second half, and their
-// partial softmaxes are merged through LDS at the end (exact: integer offsets, power-of-two factors, as the key-split
-// instantiation does through memory).  One workgroup barrier per PERIOD (= one key tile of each group); the groups run the
-// same phases in a different order inside a period, which keeps them out of phase without a second barrier:
-//       A:  QK^T(a_p)        softmax(a_p)        PV(a_p)     .
-//       B:  softmax(b_p-1)   PV(b_p-1)           .           QK^T(b_p)
-// (B carries its score accumulators across the barrier), so that a VALU phase of one wave always sits beside an MFMA phase of
-// its partner.  768 tiles = 768 workgroups = exactly 3 rounds of 256 CUs at config 2; no tail with half-empty SIMDs.
-//
-// LDS: eight half-tile buffers (K | V) x (A | B) x 2 slots; V of a B tile is needed one period later than its K and is
-// requested one period later.  A half tile holds 8 groups of 4 rows, planes interleaved per group ([group][plane][4 rows x
-// 256 B]), so that ONE statement (one M0 write, the second request at instruction offset 1024) stages both planes of the
-// wave's four rows.  Bank behaviour of the fragment reads is unchanged (addresses move by multiples of 256 B).
-// Diagnostic builds: -DUM_W8_PRIO=0 no s_setprio at all, 1 (default) priority 1 inside the MFMA phases, 2 static priority for group B.
-#ifndef UM_W8_PRIO
-#define UM_W8_PRIO 1
-#endif
-// -DUM_TRACE: lane 0 of waves 0 and 4 (group A / group B of query quarter 0) of every 37th workgroup stamps s_memtime at the section
-// boundaries of its first 24 periods (tools/trace_attn8.py): A: prepare | QK^T | bias + softmax | PV | wait | barrier;
-// B: prepare | softmax | PV | QK^T + bias | wait | barrier.
-#ifdef UM_TRACE
-#define UM8_STAMP(slot) do { if (tracing && p < 24) trace_buf[(p) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define UM8_STAMP(slot) do { } while (0)
-#endif
-template <class T, int NS>
-struct Wattn8Lds {
-    static constexpr int TK = 32;
-    static constexpr int GS = NS * 1024;             // one 4-row group: NS planes x 4 rows x 256 B
-    static constexpr int HT = 8 * GS;                // half tile: K or V of one key tile
-    static constexpr int KA = 0, VA = 2 * HT, KB = 4 * HT, VB = 6 * HT;      // + slot * HT
-    static constexpr int RING = 8 * HT;
-    static constexpr int WREG = NS * 32768;          // Wq (prologue) / Wm (epilogue) planes, linear rows
-    static constexpr int EX_OFF = WREG;              // group B's O^T: 4 waves x 16 vectors x 64 lanes x 16 B
-    static constexpr int BODY = RING > EX_OFF + 65536 ? RING : EX_OFF + 65536;
-    static constexpr int BIAS_OFF = BODY;            // [group][slot][4 query classes][TK] floats
-    static constexpr int TAB_OFF = BIAS_OFF + 4 * 512;
-    static constexpr int TAB_BYTES = 8192;           // window-local token -> (global token << 2 | mask class)
-    static constexpr int ML_OFF = TAB_OFF + TAB_BYTES;    // group B's (M, l): 4 waves x 64 lanes x 16 B
-    static constexpr int TOTAL = ML_OFF + 4096;
-};
-
-template <class T, int NS>
-__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void window_attn8_kernel(WattnArgs a) {
-    using L = Wattn8Lds<T, NS>;
-    constexpr int TK = L::TK, GS = L::GS, HT = L::HT;
-    constexpr int PSHIFT = (NS == 2) ? 14 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[L::TOTAL];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, qw = wave & 3;        // wave group (A = 0, B = 1), 32-query quarter of the tile
-    const int half = lane >> 5;
-    const float neg1 = um_opaque_neg1();
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int qt = wg % a.nqt;
-    const int win = (wg / a.nqt) % a.nwin;
-    const int s = wg / (a.nqt * a.nwin);
-    const int wy = win / a.nwx, wx = win - wy * a.nwx;
-    const bool has_mask = (a.shift_h > 0 && (wy + 1) * a.win_h == a.h) || (a.shift_w > 0 && (wx + 1) * a.win_w == a.w);
-    const float c = a.scale_log2;
-    const long sbase = (long)s * a.h * a.w;
-    const unsigned kvbase = (unsigned)(((s + a.kv_rotate) % a.streams) * a.h * a.w);
-    const int ntiles = (a.n + TK - 1) / TK;
-    const int nA = (ntiles + 1) >> 1, nB = ntiles - nA;      // key tiles [0, nA) -> group A, [nA, ntiles) -> group B; nA - nB = 0 | 1
-#ifdef UM_TRACE
-    const bool tracing = g_um_trace != nullptr && (blockIdx.x % 37) == 0 && lane == 0 && qw == 0;
-    unsigned long long* trace_buf = g_um_trace + ((size_t)(blockIdx.x / 37) * 2 + grp) * (24 * 8 + 8);
-    if (tracing) trace_buf[24 * 8] = __builtin_amdgcn_s_memtime();
-#endif
-    if (UM_W8_PRIO == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);
-
-    // ---- prologue: Wq -> LDS (linear rows, K-tile swizzle), token table, this lane's query row, Q^T = Wq . X^T -------------
-    {
-        const int row4 = lane >> 4, pc = lane & 15;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * (4 * wave + i) + row4;
-            const int cw = pc ^ (row & 15);
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wq + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cw, lds + pl * 32768 + (4 * (4 * wave + i)) * 256);
-        }
-    }
-    unsigned* tabw = reinterpret_cast<unsigned*>(lds + L::TAB_OFF);
-    const unsigned* tab = tabw;
-    {
-        const int ty0 = wy * a.win_h, tx0 = wx * a.win_w;
-        for (int tl = tid; tl < ntiles * TK; tl += 512) {
-            int ly = tl / a.win_w;
-            const int lx = tl - ly * a.win_w;
-            ly = min(ly, a.win_h - 1);                                  // past the window's last token: any valid row (masked)
-            const int ry = ty0 + ly, rx = tx0 + lx;
-            int oy = ry + a.shift_h, ox = rx + a.shift_w;
-            oy = oy >= a.h ? oy - a.h : oy;
-            ox = ox >= a.w ? ox - a.w : ox;
-            const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
-            tabw[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
-        }
-    }
-    const int tq = qt * 128 + qw * 32 + (lane & 31);
-    int clsq;
-    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
-    i16x8 qf[NS][8];
-    {
-        i16x8 xf[NS][8];
-        {
-            const float* xb = a.x + (sbase + tokq) * UM_CHANNELS + 8 * half;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(xb + 16 * ks);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + 16 * ks + 4);
-                const float y[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-                u32x4 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    hi[j] = T::pack2(y[2 * j], y[2 * j + 1]);
-                    if (NS == 2) lo[j] = T::lo2(y[2 * j], y[2 * j + 1], hi[j], neg1);
-                }
-                xf[0][ks] = __builtin_bit_cast(i16x8, hi);
-                if (NS == 2) xf[NS - 1][ks] = __builtin_bit_cast(i16x8, lo);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                              // Wq and the token table are in LDS
-        const int r = lane & 31;
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int wo = ot * (32 * 256) + r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
-                const i16x8 wh = *reinterpret_cast<const i16x8*>(lds + wo);
-                if (NS == 2) {
-                    const i16x8 wl = *reinterpret_cast<const i16x8*>(lds + 32768 + wo);
-                    acc = T::mfma(wl, xf[0][ks], acc);
-                    acc = T::mfma(wh, xf[NS - 1][ks], acc);
-                }
-                acc = T::mfma(wh, xf[0][ks], acc);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                unsigned wh[4], wl[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p0 = acc[8 * kk + 2 * j] * a.wm_scale, p1 = acc[8 * kk + 2 * j + 1] * a.wm_scale;
-                    wh[j] = T::pack2(p0, p1);
-                    if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
-                }
-                {
-                    const auto xx = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
-                    const auto yy = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
-                    const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
-                    qf[0][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
-                }
-                if (NS == 2) {
-                    const auto xx = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
-                    const auto yy = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
-                    const u32x4 f = {xx[0], yy[0], xx[1], yy[1]};
-                    qf[NS - 1][2 * ot + kk] = __builtin_bit_cast(i16x8, f);
-                }
-            }
-        }
-        __syncthreads();        // every wave is done with Wq: the buffers may take the first tiles
-    }
-
-    f32x16 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m = UM_NEG_INIT, M = -ceilf(UM_NEG_INIT * c), l = 0.f;
-
-    // ---- fragment read offsets inside a half tile (loop invariant).  They carry the GROUP's buffer base (B's buffers start at 64 KB),
-    // so that every read of the loop is register + immediate with the immediate inside the DS instructions' 16-bit offset field ----
-    int koff[8];
-    {
-        const int r = lane & 31;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) koff[ks] = grp * L::KB + (r >> 2) * GS + (r & 3) * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
-    }
-    const int li = lane & 15, lg = (lane >> 4) & 1;
-    int voff[4];
-    {
-        const int r3 = (li >> 2) & 3;                       // (row & 3) of every row this lane addresses: rows 8 half + li / 4 (+ 4, + 16 ks)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            voff[dt] = grp * L::KB + (2 * half) * GS + r3 * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
-    }
-
-    // ---- staging: wave w owns rows 4 w .. 4 w + 3 of EVERY half tile (one statement = both planes of those rows) ----------------
-    const int rowl = 4 * wave + ((lane >> 4) & 3);
-    const unsigned ssrc_k = (unsigned)(((lane & 15) ^ (rowl & 15)) << 3);
-    const unsigned ssrc_v = (unsigned)(((lane & 15) ^ ((rowl & 3) << 2)) << 3);
-    auto tile_goff = [&](int t) -> unsigned {                     // element offset of this lane's staged row of key tile t
-        return (kvbase + (tab[t * TK + rowl] >> 2)) * (unsigned)a.ldkv;
-    };
-    auto stage = [&](bool is_v, unsigned off, int buf_off) {       // off: byte offset of the row piece from the plane base
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(
-            lds + buf_off + wave * GS));
-        const unsigned short* base = is_v ? a.vp : a.kp;
-        unsigned keep;
-        if constexpr (NS == 2) {
-            const unsigned short* base1 = base + a.kv_plane_stride - 512;          // the second request's offset:1024 also moves its source
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                         "global_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(base), "s"(base1), "s"(dst) : "memory");
-        } else {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
-        }
-    };
-    // bias[class][key] of a tile: 0, the -100 mask (raw units) or "no such key"; written by the first two waves of the tile's group
-    auto bias_table = [&](int t, int slot) {
-        const bool need = has_mask || (t + 1) * TK > a.n;
-        if (need && (tid & 255) < 4 * TK) {
-            const int cq = (tid & 255) >> 5, key = tid & (TK - 1);
-            const int cls = (int)(tab[t * TK + key] & 3u);
-            const float bv = t * TK + key >= a.n ? UM_NEG_MASK : ((has_mask && cls != cq) ? a.mask_raw : 0.f);
-            reinterpret_cast<float*>(lds + L::BIAS_OFF + (2 * grp + slot) * 512)[cq * TK + key] = bv;
-        }
-    };
-
-    unsigned sokA = 0, sovA = 0, sokB = 0, sovB = 0, sovB_next = 0;
-    {   // tiles a_0 (K, V) and b_0 (K); V(b_0) goes out in period 0
-        const unsigned gA = tile_goff(0);
-        stage(false, 2u * (gA + ssrc_k), L::KA);
-        stage(true, 2u * (gA + ssrc_v), L::VA);
-        if (nB > 0) {
-            const unsigned gB = tile_goff(nA);
-            stage(false, 2u * (gB + ssrc_k), L::KB);
-            sovB_next = 2u * (gB + ssrc_v);
-        }
-        bias_table(grp ? nA : 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // addresses of what period p requests (every wave): K, V of a_p+1, K of b_p+1, V of b_p; bias table of the own group's next tile
-    // The requests are UNCONDITIONAL (no branch inside the MFMA streams they ride in: hipcc schedules per basic block): a tile
-    // past a group's last one is replaced by that last tile, whose copy lands in a buffer nobody reads any more.
-    auto prepare = [&](int p, int slot) {
-        {
-            const unsigned gA = tile_goff(min(p + 1, nA - 1));
-            sokA = 2u * (gA + ssrc_k);
-            sovA = 2u * (gA + ssrc_v);
-        }
-        sovB = sovB_next;
-        {
-            const unsigned gB = tile_goff(nA + min(p + 1, nB - 1));
-            sokB = 2u * (gB + ssrc_k);
-            sovB_next = 2u * (gB + ssrc_v);
-        }
-        const int tn = grp ? nA + p + 1 : p + 1;
-        if (p + 1 < (grp ? nB : nA)) bias_table(tn, slot ^ 1);
-    };
-    // the period's four requests, one statement each (i compile-time after unrolling)
-    auto request = [&](int i, int slot) {
-        if (i == 0) stage(false, sokA, L::KA + (slot ^ 1) * HT);
-        if (i == 1) stage(true, sovA, L::VA + (slot ^ 1) * HT);
-        if (i == 2) stage(false, sokB, L::KB + (slot ^ 1) * HT);
-        if (i == 3) stage(true, sovB, L::VB + slot * HT);
-    };
-
-    // ---- S^T = K . Q^T for the 32 keys of one tile; WITH_DMA: the period's requests ride on k-steps 0, 2, 4, 6 ---------------------
-    auto qk = [&](const unsigned char* kb, f32x16& sc, auto with_dma, int slot) {
-        constexpr bool DMA = decltype(with_dma)::value;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-        i16x8 fh[3], fl[3];
-        if (UM_W8_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            fh[ks] = *reinterpret_cast<const i16x8*>(kb + koff[ks]);
-            if (NS == 2) fl[ks] = *reinterpret_cast<const i16x8*>(kb + 1024 + koff[ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 2 < 8) {
-                fh[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + koff[ks + 2]);
-                if (NS == 2) fl[(ks + 2) % 3] = *reinterpret_cast<const i16x8*>(kb + 1024 + koff[ks + 2]);
-            }
-            if (DMA && (ks & 1) == 0) request(ks >> 1, slot);
-            if (NS == 2) {
-                sc = T::mfma(fl[ks % 3], qf[0][ks], sc);
-                sc = T::mfma(fh[ks % 3], qf[NS - 1][ks], sc);
-            }
-            sc = T::mfma(fh[ks % 3], qf[0][ks], sc);
-        }
-        constexpr int RD = NS, MF = (NS == 2) ? 3 : 1;
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 0);
-        if (UM_W8_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    };
-    const int bias_rd = L::BIAS_OFF + 2 * grp * 512 + (clsq * TK + 4 * half) * 4;
-    auto bias_add = [&](int t, int slot, f32x16& sc) {            // shifted-window mask (-100, unimatch/utils.py:106) and the ragged tail
-        if (has_mask || (t + 1) * TK > a.n) {
-            const float* bt = reinterpret_cast<const float*>(lds + bias_rd + slot * 512);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sc[4 * g + i] += bv[i];
-            }
-        }
-    };
-    // ---- online softmax of one tile's scores (see window_attn_kernel for the lazy power-of-two rescale) -> P^T operand fragments ----
-    auto softmax = [&](f32x16& sc, i16x8 (&pf)[NS][2]) {
-        float mx = sc[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-        {
-            float u, v2;
-            half_wave_pair(mx, u, v2);
-            mx = fmaxf(u, v2);
-        }
-        m = fmaxf(m, mx);
-        constexpr float LAG = (NS == 2) ? 1.f : 8.f;
-        const float Mn = -ceilf(m * c);
-        const bool move = Mn + LAG < M;
-        if (__any(move)) {
-            const float Mh = Mn - a.headroom;
-            const float resc = move ? fast_exp2(Mh - M) : 1.f;
-            M = move ? Mh : M;
-            l *= resc;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= resc;
-        }
-        const float mc = M + (float)PSHIFT;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp2(__builtin_fmaf(sc[r], c, mc));
-            sc[r] = p;
-            l += p;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int r0 = 8 * ks;
-            unsigned wh[4], wl[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float p0 = sc[r0 + 2 * j], p1 = sc[r0 + 2 * j + 1];
-                wh[j] = T::pack2(p0, p1);
-                if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
-            }
-            {
-                const auto x = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
-                const auto y = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
-                const u32x4 f = {x[0], y[0], x[1], y[1]};
-                pf[0][ks] = __builtin_bit_cast(i16x8, f);
-            }
-            if (NS == 2) {
-                const auto x = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
-                const auto y = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
-                const u32x4 f = {x[0], y[0], x[1], y[1]};
-                pf[NS - 1][ks] = __builtin_bit_cast(i16x8, f);
-            }
-        }
-    };
-    // ---- O^T += V^T . P^T; WITH_DMA: the period's requests ride on the (k-step, d-tile) groups 0, 2, 4, 6 --------------------------
-    auto pv = [&](const unsigned char* vb, const i16x8 (&pf)[NS][2], auto with_dma, int slot) {
-        constexpr bool DMA = decltype(with_dma)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        if (UM_W8_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const unsigned char* va = vb + voff[dt] + ks * 4 * GS;
-                i16x8 vh, vl;
-                {
-                    const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va));
-                    const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + GS));
-                    vh = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                if (DMA && (dt & 1) == 0) request(2 * ks + (dt >> 1), slot);
-                if (NS == 2) {
-                    const i16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 1024));
-                    const i16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 1024 + GS));
-                    vl = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = T::mfma(vl, pf[0][ks], o[dt]);
-                    o[dt] = T::mfma(vh, pf[NS - 1][ks], o[dt]);
-                }
-                o[dt] = T::mfma(vh, pf[0][ks], o[dt]);
-            }
-        }
-        {   // transpose reads two (k-step, d-tile) groups ahead of the MFMAs
-            constexpr int RD = 2 * NS, MF = 2 * NS - 1;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 1);
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MF, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, RD, 1);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF, 1);
-        }
-        if (UM_W8_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    };
-    auto period_end = [&](int p) {
-        UM8_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the period's requests has landed in LDS
-        UM8_STAMP(5);
-        __syncthreads();                                        // ... and every wave's has; the period's tiles are fully consumed
-        UM8_STAMP(6);
-    };
-    using Yes = std::true_type;
-    using No = std::false_type;
-
-    if (grp == 0) {
-        // ---- group A: one whole tile per period ---------------------------------------------------------------------------------
-        auto period_a = [&](auto slot_c, int p) {
-            constexpr int SLOT = decltype(slot_c)::value;
-            UM8_STAMP(0);
-            prepare(p, SLOT);
-            UM8_STAMP(1);
-            f32x16 sc;
-            qk(lds + L::KA + SLOT * HT, sc, Yes{}, SLOT);
-            UM8_STAMP(2);
-            bias_add(p, SLOT, sc);
-            i16x8 pf[NS][2];
-            softmax(sc, pf);
-            UM8_STAMP(3);
-            pv(lds + L::VA + SLOT * HT, pf, No{}, SLOT);
-            period_end(p);
-        };
-        for (int p = 0; p < nA; p += 2) {
-            period_a(std::integral_constant<int, 0>{}, p);
-            if (p + 1 < nA) period_a(std::integral_constant<int, 1>{}, p + 1);
-        }
-    } else {
-        // ---- group B: softmax + PV of the previous tile, then QK^T of this period's tile (scores carried across the barrier) -------
-        f32x16 sc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-        {   // period 0: nothing to finish yet
-            prepare(0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) request(i, 0);
-            if (nB > 0) {
-                qk(lds + L::KA, sc, No{}, 0);
-                bias_add(nA, 0, sc);
-            }
-            period_end(0);
-        }
-        auto period_b = [&](auto slot_c, int p) {               // 1 <= p < nB
-            constexpr int SLOT = decltype(slot_c)::value;
-            UM8_STAMP(0);
-            prepare(p, SLOT);
-            UM8_STAMP(1);
-            i16x8 pf[NS][2];
-            softmax(sc, pf);
-            UM8_STAMP(2);
-            pv(lds + L::VA + (SLOT ^ 1) * HT, pf, Yes{}, SLOT);
-            UM8_STAMP(3);
-            qk(lds + L::KA + SLOT * HT, sc, No{}, SLOT);
-            bias_add(nA + p, SLOT, sc);
-            period_end(p);
-        };
-        for (int p = 1; p < nB; p += 2) {
-            period_b(std::integral_constant<int, 1>{}, p);
-            if (p + 1 < nB) period_b(std::integral_constant<int, 0>{}, p + 1);
-        }
-        if (nB > 0) {   // the last tile's softmax + PV: inside period nB when group A has one tile more, behind the loop otherwise
-            i16x8 pf[NS][2];
-            softmax(sc, pf);
-            pv(lds + L::VA + ((nB - 1) & 1) * HT, pf, No{}, 0);       // (slot at run time: four additions, once per workgroup)
-        }
-        if (nA > nB) period_end(nB);
-    }
-
-    // ---- merge of the two partial softmaxes through LDS; epilogue by group A ------------------------------------------------------
-#ifdef UM_TRACE
-    if (tracing) trace_buf[24 * 8 + 1] = __builtin_amdgcn_s_memtime();
-#endif
-    if (grp == 0) {
-        // group A's buffers are dead behind the last period's barrier: Wm -> [0, NS x 32 KB) while group B finishes
-        const int row4 = lane >> 4, pc = lane & 15;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 4 * (8 * qw + i) + row4;               // wave qw stages rows 32 qw .. 32 qw + 31
-            const int cc = pc ^ (row & 15);
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl)
-                lds_dma16(a.wm + pl * a.wm_plane_stride + row * UM_CHANNELS + 8 * cc, lds + pl * 32768 + (4 * (8 * qw + i)) * 256);
-        }
-    }
-    __syncthreads();                                               // E0: every buffer of group B is dead as well
-    if (grp == 1) {
-        unsigned char* ex = lds + L::EX_OFF + qw * 16384 + lane * 16;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(ex + (4 * dt + g) * 1024) = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(lds + L::ML_OFF + qw * 1024 + lane * 16) = f32x4{M, l, 0.f, 0.f};
-    }
-    __syncthreads();                                               // E1
-    if (grp == 1) {
-        __syncthreads();                                           // E2 (group A's Wm pieces): group B only keeps the count
-        return;
-    }
-    if (nB > 0) {
-        const f32x4 ml = *reinterpret_cast<const f32x4*>(lds + L::ML_OFF + qw * 1024 + lane * 16);
-        const float Mo = ml[0], lo = ml[1];
-        const float Ms = fminf(M, Mo);                              // offsets are integers: the factors are powers of two
-        const float fa = fast_exp2(Ms - M), fb = fast_exp2(Ms - Mo);
-        l = l * fa + lo * fb;
-        M = Ms;
-        const unsigned char* ex = lds + L::EX_OFF + qw * 16384 + lane * 16;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(ex + (4 * dt + g) * 1024);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[dt][4 * g + i] = o[dt][4 * g + i] * fa + w[i] * fb;
-            }
-    }
-    float lt;
-    {
-        float u, v2;
-        half_wave_pair(l, u, v2);
-        lt = u + v2;
-    }
-    const float inv = 1.0f / lt;
-    // ---- out = LayerNorm(message . Wm^T) (+ residual), message = O / l still in the accumulators (as window_attn_kernel<MERGE>) --
-    i16x8 of[NS][8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int dt = ks >> 1, r0 = 8 * (ks & 1);
-        unsigned wh[4], wl[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float p0 = o[dt][r0 + 2 * j] * inv, p1 = o[dt][r0 + 2 * j + 1] * inv;
-            wh[j] = T::pack2(p0, p1);
-            if (NS == 2) wl[j] = T::lo2(p0, p1, wh[j], neg1);
-        }
-        {
-            const auto x = __builtin_amdgcn_permlane32_swap(wh[0], wh[2], false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(wh[1], wh[3], false, false);
-            const u32x4 f = {x[0], y[0], x[1], y[1]};
-            of[0][ks] = __builtin_bit_cast(i16x8, f);
-        }
-        if (NS == 2) {
-            const auto x = __builtin_amdgcn_permlane32_swap(wl[0], wl[2], false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(wl[1], wl[3], false, false);
-            const u32x4 f = {x[0], y[0], x[1], y[1]};
-            of[NS - 1][ks] = __builtin_bit_cast(i16x8, f);
-        }
-    }
-    f32x16 yv[4];
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[ot][r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                               // E2: Wm is in LDS
-    {
-        const int r = lane & 31;
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int wo = ot * (32 * 256) + r * 256 + (((2 * ks + half) ^ (r & 15)) << 4);
-                const i16x8 wh = *reinterpret_cast<const i16x8*>(lds + wo);
-                if (NS == 2) {
-                    const i16x8 wl = *reinterpret_cast<const i16x8*>(lds + 32768 + wo);
-                    yv[ot] = T::mfma(wl, of[0][ks], yv[ot]);
-                    yv[ot] = T::mfma(wh, of[NS - 1][ks], yv[ot]);
-                }
-                yv[ot] = T::mfma(wh, of[0][ks], yv[ot]);
-            }
-    }
-    float s1 = 0.f;
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            yv[ot][r] *= a.wm_scale;
-            s1 += yv[ot][r];
-        }
-    float u, v2;
-    half_wave_pair(s1, u, v2);
-    const float mean = (u + v2) * (1.0f / 128.0f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = yv[ot][r] - mean;
-            s2 = __builtin_fmaf(d, d, s2);
-        }
-    half_wave_pair(s2, u, v2);
-    const float rstd = 1.0f / sqrtf((u + v2) * (1.0f / 128.0f) + a.eps);
-    if (tq < a.n) {
-        float* ob = a.out + (sbase + tokq) * UM_CHANNELS + 4 * half;
-        const float* rb = a.residual ? a.residual + (sbase + tokq) * UM_CHANNELS + 4 * half : nullptr;
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * ot + 8 * g;
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + n + 4 * half);
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + n + 4 * half);
-                f32x4 y;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (yv[ot][4 * g + i] - mean) * rstd * gm[i] + bt[i];
-                if (rb) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rb + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] += rr[i];
-                }
-                *reinterpret_cast<f32x4*>(ob + n) = y;
-            }
-    }
-#ifdef UM_TRACE
-    if (tracing) trace_buf[24 * 8 + 2] = __builtin_amdgcn_s_memtime();
-#endif
-}
-
-#endif  // UM_WATTN_W8
+// (Round 5 built window_attn8_kernel here -- one 8-wave workgroup per CU and query tile, two wave groups in anti-phase, exactly three rounds
+// at config 2 -- parity-green, measured +4.7 % slower than the kernel above, and removed it: profiles/r05_attention_experiments.txt has the
+// design, the same-call timings and the section stamps; the code is in git at 06bbabb .. 4c4d2cd.)
 
 // ------------------------------------------------------------------------------------ host side
 extern void um_set_error(const char* fmt, ...);
@@ -1746,20 +1107,6 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
         // the layer kernel (query projection + attention + merge + LayerNorm): wattn_plan; without workspace one workgroup per tile
         WattnPlan p = wattn_plan(a.total, (a.n + 31) / 32, ks_ws != nullptr);
         if (p.rem > 0 && ks_ws_bytes < wattn_ks_bytes(p.rem, p.split)) p = WattnPlan{a.total, 0, 1};
-        // big launches with enough key tiles to halve: one 8-wave workgroup per query tile (window_attn8_kernel); its token table
-        // holds windows of up to 2048 tokens
-#if UM_WATTN_W8
-        static const bool no_w8 = um_debug_env("UM_WATTN_NO_W8") != nullptr;      // A/B switch (diagnostic builds)
-        const int ntiles = (a.n + 31) / 32;
-        if (p.rem == 0 && !no_w8 && ntiles >= 8 && ntiles * 32 * 4 <= 8192) {
-            um_census_hit(UM_V_WATTN_W8);
-            if (mode == 0)
-                hipLaunchKernelGGL((window_attn8_kernel<Fp16, 2>), dim3(p.full), dim3(512), 0, stream, a);
-            else
-                hipLaunchKernelGGL((window_attn8_kernel<Bf16, 1>), dim3(p.full), dim3(512), 0, stream, a);
-            return (int)hipGetLastError();
-        }
-#endif
         if (p.rem == 0) {
             um_census_hit(UM_V_WATTN_TILE);
             if (mode == 0)
