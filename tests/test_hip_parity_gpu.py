@@ -1390,6 +1390,21 @@ def test_concurrent_forwards_on_two_streams():
             lo += n
         assert torch.isfinite(first).all()
         assert (first - whole).abs().max().item() < 1e-3 * max(1.0, whole.abs().max().item())
+        if name == 'gmflow_s1':
+            # a new backend (other precision: every shared cache entry is rebuilt) sends the next forward through the sequential path
+            # again; the concurrent ones after it are bitwise that result
+            model.set_precision('fast')
+            fast_first = wrapped(i0, i1, **kw)['flow_preds'][0]
+            assert wrapped._backend[1] is not None and wrapped._backend[0] == id(model.ops)
+            fast_runs = [wrapped(i0, i1, **kw)['flow_preds'][0] for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(r, fast_first) for r in fast_runs)
+            gen = model.ops.cache_generation
+            model.invalidate_weights()
+            assert model.ops.cache_generation > gen
+            again = wrapped(i0, i1, **kw)['flow_preds'][0]            # sequential (the state of the backend changed), rebuilds
+            assert torch.equal(again, fast_first)
+            model.set_precision('exact')
 
 
 def _refine_model(name, gain=0.02):

@@ -143,6 +143,7 @@ class HipOps:
         workspace (a launch that was cut short -- aborted capture, device error -- may have left arrival counters non-zero)."""
         self._wcache.clear()
         self.__dict__.pop('_split_ws', None)
+        self.cache_generation = getattr(self, 'cache_generation', 0) + 1
 
     def _cache_put(self, key, tensors, value):
         if len(self._wcache) > 256:
@@ -150,6 +151,9 @@ class HipOps:
             if len(self._wcache) > 256:
                 self._wcache.clear()
         self._wcache[key] = (tuple(weakref.ref(t) for t in tensors), value)
+        # counts the builds of shared (stream-independent) cache entries: ConcurrentUniMatch only runs its parts on separate streams
+        # when the previous forward built none -- an entry is written on the stream that first needs it
+        self.cache_generation = getattr(self, 'cache_generation', 0) + 1
         return value
 
     def weight_planes(self, weights):

@@ -21,8 +21,10 @@ class ConcurrentUniMatch(torch.nn.Module):
     contiguous sample ranges, each on its own stream, joined on the caller's stream.
 
     The first forward of a geometry / argument set / parameter version runs the parts one after the other on the caller's stream:
-    that is the forward that builds the caches later forwards only read (weight planes, position tables, plane buffers are keyed per
-    stream where they are written per forward) -- concurrent first use would race on them."""
+    that is the forward that builds the caches later forwards only read (weight planes, position tables; buffers that are written per
+    forward are kept per stream) -- concurrent first use would race on them.  The same after anything that makes the backend rebuild
+    shared entries (``set_precision``, ``invalidate_weights``, a weight edited in place): the parts only go to separate streams when the
+    backend object is the one of the previous forward and that forward built no shared cache entry (``HipOps.cache_generation``)."""
 
     def __init__(self, model, parts=2):
         super().__init__()
@@ -32,6 +34,11 @@ class ConcurrentUniMatch(torch.nn.Module):
         self.parts = parts
         self._streams = {}
         self._seen = set()
+        self._backend = None                     # (id of the model's backend, its cache generation) after the previous forward
+
+    def _backend_state(self):
+        ops = getattr(self.model, 'ops', None)                     # (UniMatch creates its backend on first use)
+        return (id(ops), getattr(ops, 'cache_generation', None))
 
     def _key(self, img0, kw):
         version = sum(p._version for p in self.model.parameters())
@@ -54,7 +61,7 @@ class ConcurrentUniMatch(torch.nn.Module):
             return shard_batch(img0, r, n), shard_batch(img1, r, n), pk
 
         key = self._key(img0, kw)
-        concurrent = img0.is_cuda and key in self._seen
+        concurrent = img0.is_cuda and key in self._seen and self._backend is not None and self._backend == self._backend_state()
         outs = []
         if not concurrent:
             for r in range(n):
@@ -77,6 +84,7 @@ class ConcurrentUniMatch(torch.nn.Module):
                 cur.wait_stream(streams[r])
                 for t in outs[r]:
                     t.record_stream(cur)                            # allocated on the part's stream, consumed on the caller's
+        self._backend = self._backend_state()
         # every prediction of the list: [bidir * b_r, ...] per part -> [bidir * batch, ...] in the reference's [forward; backward] order
         counts = [shard_bounds(batch, r, n)[1] - shard_bounds(batch, r, n)[0] for r in range(n)]
         preds = []
