@@ -28,10 +28,13 @@ no per-kernel event inside.  Directly after it a BREAKDOWN pass runs the same K 
 (``um_timing_*``, recorded on the launch stream): once timing only the launches inside the CNN encoder, once only those outside it.
 
 Extra objects on the line:
+  serial                throughput of the same K steps as ONE forward of the per-GPU batch per step (``config.streams`` = 1 when the
+                        headline itself ran that way): the mode of every per-kernel figure below -- in the concurrent mode the
+                        durations of kernels that share the GPU overlap and do not price a kernel.
   roofline              the dominant HIP kernel (windowed attention): algorithmic FLOPs per launch / its mean
-                        launch duration from the breakdown pass, against the dense 16-bit MFMA peak; ``traffic`` / ``mfma_busy``
-                        come from a rocprofv3 PMC pass kept in profiles/ and are nulled when the kernel source has changed
-                        since that pass.  ``frac`` prices attention proper (4 L n C per stream); the merge Linear and query
+                        launch duration from the breakdown pass, against the dense 16-bit MFMA peak; ``traffic`` / ``mfma_busy`` /
+                        ``lds_busy`` / ``valu_busy`` come from rocprofv3 PMC passes kept in profiles/ and are nulled when the kernel
+                        source has changed since those passes.  ``frac`` prices attention proper (4 L n C per stream); the merge Linear and query
                         projection the same launch executes are in ``with_fused_linears``.
   roofline_global_corr  the same for ``gsv4_kernel`` (global correlation / propagation: the kernel the north star names).
   roofline_ffn          the same for ``ffn_kernel`` (the whole Transformer FFN in one launch, transformer.py:141-144).
