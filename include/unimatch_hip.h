@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define UM_VERSION 211
+#define UM_VERSION 220
 
 #define UM_MODE_EXACT 0
 #define UM_MODE_FAST 1
@@ -116,6 +116,15 @@ int um_range_flags(unsigned* flags_out, int reset);
 #define UM_V_COUNT 14
 int um_census_enable(int on);
 long um_census_count(int variant);
+/* Key-tile census of the window attention (round 6; diagnostic, off by default).  In a window that carries the shifted-window mask
+ * (unimatch/utils.py:84-108) a (128-query workgroup, 32-key tile) pair whose classes differ holds nothing but -100 logits
+ * (unimatch/attention.py:88-89); the kernel walks such windows class by class, PROBES those tiles (hi.hi product only) after the
+ * workgroup's own-class tiles and drops a tile iff every probed logit stays UM margin (40 natural-log units) below the running
+ * row maximum -- otherwise the tile is computed exactly as an unmasked one.  While enabled, every workgroup adds to four counters
+ * of the current device: [0] key tiles computed in full, [1] tiles probed, [2] probed tiles that then had to be computed (they are
+ * part of [0] as well), [3] workgroups.  um_window_attn_tile_census(enable, counts4): counts4 != NULL synchronises the device,
+ * copies the counters out and zeroes them; then the census is switched on / off as `enable` says. */
+int um_window_attn_tile_census(int enable, unsigned long long* counts4);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 /* ===================================== end of the measurement ABI ============================= */

@@ -151,6 +151,99 @@ def test_window_attention_forced_rescale_and_mask_dominance(ops):
     assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item())
 
 
+def _census(fn):
+    """Run fn() with the key-tile census on; returns (result, counters)."""
+    from unimatch_amd import _abi
+    _abi.attn_tile_census(True)
+    try:
+        out = fn()
+    finally:
+        counts = _abi.attn_tile_census(False)
+    return out, counts
+
+
+def test_window_attention_masked_tile_skip_margin_and_fallback(ops, ops_fast):
+    """Round 6: wholly masked (query workgroup, key tile) pairs are probed and dropped only under a bound.  Geometry with
+    class-uniform tiles (64x32 map, 2x2 windows of 32x16 = 512 tokens, shift 16/8: class sizes 512 | 256+256 | 256+256 | 4 x 128).
+    (a) random data: every masked tile is dropped, the census is the closed form, the result is the oracle's;
+    (b) one masked key whose logit sits 41 below the row maximum (-100 included): still dropped; 39 below: the tile is computed;
+    (c) a masked key that must WIN the softmax (logit 318 - 100 above everything): the fallback computes it and it dominates;
+    (d) one class of keys scaled by 12: many probes fail, result still the oracle's."""
+    s, h, w, wh, ww, sh, sw = 2, 64, 32, 32, 16, 16, 8
+    n, tiles = wh * ww, wh * ww // 32
+    q, k, v = (rnd(50 + i, s, h * w, C) for i in range(3))
+    idx, label = hp.window_index(h, w, wh, ww, sh, sw)
+
+    def run(o, q_, k_, v_):
+        want = hp.window_attention(q_.double(), k_.double(), v_.double(), h, w, wh, ww, sh, sw)
+        got, counts = _census(lambda: o.window_attention(q_.to(DEV), k_.to(DEV), v_.to(DEV), h, w, wh, ww, sh, sw))
+        return want, got, counts
+
+    # closed form of the census: per stream 4 windows x 4 workgroups; masked tiles per workgroup 0 / 8 / 8 / 12 of 16
+    probed_all = s * 4 * (0 + 8 + 8 + 12)
+    full_all = s * 4 * (16 + 8 + 8 + 4)
+    for o, tol in ((ops, 5e-5), (ops_fast, None)):
+        want, got, c = run(o, q, k, v)
+        assert c == {'full': full_all, 'probed': probed_all, 'probed_then_computed': 0, 'workgroups': s * 16}, c
+        if tol:
+            assert err(got, want)[0] < tol * max(1.0, want.abs().max().item())
+        else:
+            assert err(got, want)[1] < 3e-2 * want.abs().mean().item() + 1e-3
+    # (b) margins 41 and 39 around the threshold of 40: query a of the corner window, own-class logits exactly 0 (channel 0 of every
+    # key is 0, the query is e0 * x), ONE key of another class with logit x*y/sqrt(C) - 100 = -40 -/+ 1
+    win = idx.shape[0] - 1
+    a = int(idx[win, 0])
+    other = [int(idx[win, j]) for j in range(n) if label[win, j] != label[win, 0]]
+    for delta, expect_computed in ((-1.0, 0), (+1.0, 1)):
+        q2, k2 = q.clone(), k.clone()
+        x = math.sqrt((60.0 + delta) * math.sqrt(C))
+        q2[0, a] = 0.0
+        q2[0, a, 0] = x
+        k2[:, :, 0] = 0.0
+        k2[0, other[5], 0] = x
+        want, got, c = run(ops, q2, k2, v)
+        assert c['probed'] == probed_all and c['probed_then_computed'] == expect_computed, (delta, c)
+        assert c['full'] == full_all + expect_computed
+        assert err(got, want)[0] < 5e-5 * max(1.0, want.abs().max().item())
+    # (c) mask dominance through the fallback
+    q2, k2 = q.clone(), k.clone()
+    q2[0, a] = 0.0
+    q2[0, a, 0] = 60.0
+    k2[:, :, 0] = 0.0
+    k2[0, other[-1], 0] = 60.0
+    for o in (ops, ops_fast):
+        want, got, c = run(o, q2, k2, v)
+        assert c['probed_then_computed'] == 1, c
+        assert (want[0, a] - v[0, other[-1]].double()).abs().max() < 1e-6
+        assert (got[0, a].cpu().double() - v[0, other[-1]].double()).abs().max() < (1e-4 if o is ops else 3e-2)
+        if o is ops:
+            assert err(got, want)[0] < 1e-4 * max(1.0, want.abs().max().item())
+    # (d) a whole class of loud keys: the keys of the wrapped columns x 12 -> logits of std 12, maxima ~ 40-45 above the quiet own
+    # class; shifted so that the threshold of 60 cuts through the distribution
+    k3 = k.clone()
+    wrapped = torch.zeros(h * w, dtype=torch.bool)
+    wrapped[idx[label % 3 == 2]] = True                  # column band 2 of unimatch/utils.py:95-100
+    k3[:, wrapped] *= 16.0
+    want, got, c = run(ops, q, k3, v)
+    assert 0 < c['probed_then_computed'] < c['probed'], c
+    assert err(got, want)[0] < 5e-5 * max(1.0, want.abs().max().item())
+
+
+def test_window_attention_tile_census_at_config2_size(ops):
+    """At BASELINE config 2's layer geometry (64x96, 2x2 windows of 1536 tokens, shift 16/24) the shifted launch computes 56.25 % of
+    its key tiles and probes the rest; the unshifted one computes all; both equal the fp64 oracle on one stream."""
+    s, h, w, wh, ww = 2, 64, 96, 32, 48
+    q, k, v = rnd(60, s, h * w, C, scale=1.5), rnd(61, s, h * w, C, scale=1.5), rnd(62, s, h * w, C)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    got0, c0 = _census(lambda: ops.window_attention(qd, kd, vd, h, w, wh, ww, 0, 0))
+    assert c0 == {'full': s * 4 * 12 * 48, 'probed': 0, 'probed_then_computed': 0, 'workgroups': s * 48}, c0
+    got1, c1 = _census(lambda: ops.window_attention(qd, kd, vd, h, w, wh, ww, 16, 24))
+    assert c1 == {'full': s * 12 * (48 + 24 + 24 + 12), 'probed': s * 12 * (24 + 24 + 36), 'probed_then_computed': 0,
+                  'workgroups': s * 48}, c1
+    want = hp.window_attention(q.double(), k.double(), v.double(), h, w, wh, ww, 16, 24)
+    assert err(got1, want)[0] < 5e-5 * max(1.0, want.abs().max().item())
+
+
 def test_window_attention_properties_at_config2_size(ops, ops_fast):
     """Size-independent properties at BASELINE config 2's layer size (2B=4 here to bound memory): 64x96 map,
     2x2 windows of 1536 tokens.  (a) constant v -> same constant; (b) k = 0 -> plain window mean of v,

@@ -174,7 +174,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_abi.SIGNATURES) == names                     # the ctypes table mirrors the header
-    assert _abi.load().um_version() == 211
+    assert _abi.load().um_version() == 220
     # harness / product separation: hardware micro-benchmarks exist in diagnostic builds only
     assert not any(n.startswith('um_debug_') for n in names)
     assert sorted(_abi.DIAG_SIGNATURES) == declared_symbols(diagnostic=True)

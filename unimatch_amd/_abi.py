@@ -90,6 +90,7 @@ SIGNATURES = {
     'um_depth_corr_softmax': (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
     'um_census_enable': (_c_int, [_c_int]),
     'um_census_count': (ctypes.c_long, [_c_int]),
+    'um_window_attn_tile_census': (_c_int, [_c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
     'um_swin_attn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_attn1d_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_local_corr_softmax_1d': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
@@ -167,6 +168,14 @@ def census(lib=None):
     """Launch counts since the last ``um_census_enable(1)`` as ``{name: count}``."""
     lib = lib or load()
     return {k: int(lib.um_census_count(v)) for k, v in CENSUS.items()}
+
+
+def attn_tile_census(enable):
+    """``um_window_attn_tile_census``: read-and-zero the key-tile counters of the current device, then switch the census on / off.
+    Returns ``{'full', 'probed', 'probed_then_computed', 'workgroups'}``."""
+    out = (ctypes.c_ulonglong * 4)()
+    check(load().um_window_attn_tile_census(1 if enable else 0, out), 'um_window_attn_tile_census')
+    return dict(zip(('full', 'probed', 'probed_then_computed', 'workgroups'), (int(v) for v in out)))
 
 
 def check(code, what):

@@ -89,6 +89,11 @@ struct WattnArgs {
     float* ks_part;              // [split tiles][split][17][256][4] fp32: O^T (16 vectors), (M, l, -, -) of every part
     unsigned* ks_flag;           // [split tiles] arrival counters, zero between launches
     unsigned* range_flag;        // um_range_flags: sticky operand-range word (device address; nullptr: none)
+    // Round 6: masked-tile skip (see "class-major order" below)
+    float skip_raw;              // a wholly masked key tile is dropped iff its hi.hi probe stays <= m_run + skip_raw  (raw q.k units;
+                                 //   (100 - margin) * sqrt(C), margin = UM_WATTN_SKIP_MARGIN); < 0: never (every tile is computed)
+    int spx;                     // > 0: streams per XCD for the heaviest-window-first grid order (0: natural order)
+    unsigned long long* tile_census;   // nullptr, or 4 counters: tiles computed in full / probed / probed and then computed / workgroups
 };
 
 // window-local token -> global token index and its mask class.
@@ -104,6 +109,42 @@ __device__ __forceinline__ int window_token(const WattnArgs& a, int wy, int wx, 
     const int rb = (a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0;
     const int cb = (a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0;
     cls = 2 * rb + cb;
+    return oy * a.w + ox;
+}
+
+// ---- class-major order of a window's tokens (round 6) -----------------------------------------------------------------------------
+// Softmax is invariant under a permutation of the keys and queries are independent, so the ORDER in which a workgroup walks its
+// window is free.  In a window that carries the shift mask the tokens are laid out class by class -- class 0 (rows < R0, columns
+// < C0 of the window), then 1 (columns >= C0), 2 (rows >= R0), 3 -- each class row-major inside its rectangle.  With that order a
+// 32-key tile and a 128-query workgroup are uniformly of ONE class whenever the class sizes are multiples of 32 / 128 (config 2:
+// 768 | 768 and 4 x 384), and a (query tile, key tile) pair of different classes is a block of nothing but -100 logits
+// (unimatch/utils.py:84-108, unimatch/attention.py:88-89): 43.75 % of a shifted launch at K = 2.  Windows without the mask have
+// R0 = win_h, C0 = win_w: one class, plain row-major order.
+struct WinClasses {
+    int R0, C0;              // first row / column of the wrapped band inside this window (win_h / win_w: none)
+    int e0, e1, e2;          // class-major positions at which classes 1, 2, 3 begin
+};
+__device__ __forceinline__ WinClasses win_classes(const WattnArgs& a, int wy, int wx) {
+    WinClasses k;
+    k.R0 = (a.shift_h > 0 && (wy + 1) * a.win_h == a.h) ? a.win_h - a.shift_h : a.win_h;
+    k.C0 = (a.shift_w > 0 && (wx + 1) * a.win_w == a.w) ? a.win_w - a.shift_w : a.win_w;
+    k.e0 = k.R0 * k.C0;
+    k.e1 = k.R0 * a.win_w;
+    k.e2 = k.e1 + (a.win_h - k.R0) * k.C0;
+    return k;
+}
+__device__ __forceinline__ int cm_class(const WinClasses& k, int p) { return (p >= k.e0 ? 1 : 0) + (p >= k.e1 ? 1 : 0) + (p >= k.e2 ? 1 : 0); }
+// class-major position p (< n) of window (wy, wx) -> global token index and mask class
+__device__ __forceinline__ int cm_token(const WattnArgs& a, const WinClasses& k, int wy, int wx, int p, int& cls) {
+    cls = cm_class(k, p);
+    const int start = cls == 0 ? 0 : (cls == 1 ? k.e0 : (cls == 2 ? k.e1 : k.e2));
+    const int cw = (cls & 1) ? a.win_w - k.C0 : k.C0;
+    const int idx = p - start;
+    const int iy = idx / cw, ix = idx - iy * cw;
+    const int ry = wy * a.win_h + ((cls & 2) ? k.R0 : 0) + iy, rx = wx * a.win_w + ((cls & 1) ? k.C0 : 0) + ix;
+    int oy = ry + a.shift_h, ox = rx + a.shift_w;
+    oy = oy >= a.h ? oy - a.h : oy;
+    ox = ox >= a.w ? ox - a.w : ox;
     return oy * a.w + ox;
 }
 
@@ -159,10 +200,40 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     } else {
         wg = xcd_remap(blockIdx.x, gridDim.x);
     }
-    const int qt = wg % a.nqt;
-    const int win = (wg / a.nqt) % a.nwin;
-    const int s = wg / (a.nqt * a.nwin);
-    const int wy = win / a.nwx, wx = win - wy * a.nwx;
+    int qt, s, wy, wx;
+    if (!KSPLIT && a.spx > 0) {
+        // Heaviest windows first (round 6).  With the masked tiles dropped a workgroup of an interior window does 100 % of the
+        // key walk, one of a last-column / last-row window ~58 %, one of the corner window ~37 %; the launch is 1.5 rounds of the
+        // resident slots, so the order decides what the tail is made of.  Every XCD keeps its own `spx` streams (xcd_remap hands
+        // XCD x the ids [x * per, (x + 1) * per)); inside them the order is window class, stream, query tile: interior windows,
+        // last column, last row, corner.
+        const int per = a.spx * a.nwin * a.nqt;
+        const int xcd = wg / per, i = wg - xcd * per;
+        const int wr = i / (a.spx * a.nqt), r2 = i - wr * (a.spx * a.nqt);
+        const int sl = r2 / a.nqt;
+        qt = r2 - sl * a.nqt;
+        s = xcd * a.spx + sl;
+        const int nwy = a.nwin / a.nwx, nA = (nwy - 1) * (a.nwx - 1);
+        if (wr < nA) {
+            wy = wr / (a.nwx - 1);
+            wx = wr - wy * (a.nwx - 1);
+        } else if (wr < nA + nwy - 1) {
+            wy = wr - nA;
+            wx = a.nwx - 1;
+        } else if (wr < a.nwin - 1) {
+            wy = nwy - 1;
+            wx = wr - nA - (nwy - 1);
+        } else {
+            wy = nwy - 1;
+            wx = a.nwx - 1;
+        }
+    } else {
+        qt = wg % a.nqt;
+        const int win = (wg / a.nqt) % a.nwin;
+        s = wg / (a.nqt * a.nwin);
+        wy = win / a.nwx;
+        wx = win - wy * a.nwx;
+    }
     const bool has_mask = (a.shift_h > 0 && (wy + 1) * a.win_h == a.h) || (a.shift_w > 0 && (wx + 1) * a.win_w == a.w);
     const float c = a.scale_log2;
     const long sbase = (long)s * a.h * a.w;
@@ -192,26 +263,38 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     const bool use_tab = ntiles * TK * 4 <= TAB_BYTES;                  // uniform
     const unsigned* tab = reinterpret_cast<const unsigned*>(lds + 2 * BUF);
-    if (use_tab) {
-        const int ty0 = wy * a.win_h, tx0 = wx * a.win_w;
+    const WinClasses wc = win_classes(a, wy, wx);
+    if (use_tab) {                                                      // class-major order (see cm_token)
         for (int tl = tid; tl < ntiles * TK; tl += 256) {
-            int ly = tl / a.win_w;
-            const int lx = tl - ly * a.win_w;
-            ly = min(ly, a.win_h - 1);                                  // past the window's last token: any valid row (masked)
-            const int ry = ty0 + ly, rx = tx0 + lx;
-            int oy = ry + a.shift_h, ox = rx + a.shift_w;
-            oy = oy >= a.h ? oy - a.h : oy;
-            ox = ox >= a.w ? ox - a.w : ox;
-            const int cls = 2 * ((a.shift_h > 0 && ry >= a.h - a.shift_h) ? 1 : 0) + ((a.shift_w > 0 && rx >= a.w - a.shift_w) ? 1 : 0);
-            reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)(oy * a.w + ox) << 2) | (unsigned)cls;
+            int cls;
+            const int tokn = cm_token(a, wc, wy, wx, min(tl, a.n - 1), cls);    // past the window's last token: any valid row (masked)
+            reinterpret_cast<unsigned*>(lds + 2 * BUF)[tl] = ((unsigned)tokn << 2) | (unsigned)cls;
         }
         if (!QPROJ) __syncthreads();                                    // QPROJ: the prologue's barriers below cover it
     }
+    // ---- which key tiles this workgroup computes, probes, or may drop (class-major windows only) -----------------------------
+    //   own_pure: tiles uniformly of the workgroup's own query class       -> computed, and without the bias table;
+    //   probe   : tiles uniformly of ANOTHER class (every logit carries -100) -> probed after the own tiles (see the probe phase);
+    //   the rest (tiles that straddle a class boundary, or a workgroup whose 128 queries are of two classes): computed with the
+    //   per-lane bias table as before.
+    // All wave-uniform (ballots); tile index = bit index, at most 64 tiles because the token table holds 2048 tokens.
+    unsigned long long own_pure = 0, probe = 0;
+    if (!KSPLIT && has_mask && use_tab) {
+        const int q0 = qt * 128, q1 = min(q0 + 127, a.n - 1);
+        const int cq = cm_class(wc, q0);
+        if (cq == cm_class(wc, q1)) {
+            const int p0 = min(lane * TK, a.n - 1), p1 = min(lane * TK + TK - 1, a.n - 1);
+            const int cf = cm_class(wc, p0), cl = cm_class(wc, p1);
+            own_pure = __ballot(lane < ntiles && cf == cl && cf == cq);
+            if (a.skip_raw >= 0.f) probe = __ballot(lane < ntiles && cf == cl && cf != cq);
+        }
+    }
+    const bool bymask = !KSPLIT && use_tab;                             // tile walk driven by a bit mask (else: the range [t0, t1))
 
     // ---- this lane's query -----------------------------------------------------------------------
     const int tq = qt * 128 + wave * 32 + (lane & 31);
     int clsq;
-    const int tokq = window_token(a, wy, wx, min(tq, a.n - 1), clsq);
+    const int tokq = use_tab ? cm_token(a, wc, wy, wx, min(tq, a.n - 1), clsq) : window_token(a, wy, wx, min(tq, a.n - 1), clsq);
     // per-lane LDS read offsets of an A-operand row tile (K tile, Wm / Wq rows): loop invariant
     int koff[8];
     {
@@ -342,6 +425,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         bly = key / a.win_w;
         blx = key - bly * a.win_w;
     }
+    // the additive bias table of tile t is needed for the ragged tail and for every tile that is not uniformly of the workgroup's
+    // own class
+    auto need_bias = [&](int t) -> bool { return (t + 1) * TK > a.n || (has_mask && !((own_pure >> t) & 1ull)); };
     auto token_at = [&](int ly, int lx, int& cls) -> int {             // (ly, lx) may run past the window: clamp
         ly = min(ly, a.win_h - 1);
         const int ry = y0 + ly, rx = x0 + lx;
@@ -368,7 +454,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     unsigned sok[2], sov[2];                                             // UM_WATTN_OFF32: byte offsets from a.kp / a.vp
     auto stage_prepare = [&](int t, unsigned char* base) {
         // bias[class][key]: 0, the -100 mask (raw units), or "no such key"; only tiles that need it read it
-        const bool need = has_mask || (t + 1) * TK > a.n;
+        const bool need = need_bias(t);
         if (use_tab) {
             const unsigned* tp = tab + t * TK + 8 * wave + ((lane >> 4) & 3);
 #pragma unroll
@@ -455,19 +541,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             voff[dt] = rowb * 256 + ((((dt ^ r3) << 2) + 2 * lg + ((li & 3) >> 1)) << 4) + 8 * (li & 1);
     }
 
-    stage_prepare(t0, lds);
-#pragma unroll
-    for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // One tile.  SLOT is a compile-time constant so that every LDS offset of the tile is an instruction immediate.
-    auto tile = [&](auto slot_c, int t) {
+    // One tile.  SLOT is a compile-time constant so that every LDS offset of the tile is an instruction immediate.  tn = the tile
+    // that follows in this workgroup's walk (staged into the other slot meanwhile), < 0: none.
+    auto tile = [&](auto slot_c, int t, int tn) {
         constexpr int SLOT = decltype(slot_c)::value;
         UM_STAMP(0);
-        const bool staging = t + 1 < t1;
+        const bool staging = tn >= 0;
         unsigned char* nxt = lds + (SLOT ^ 1) * BUF;
-        if (staging) stage_prepare(t + 1, nxt);
+        if (staging) stage_prepare(tn, nxt);
         const unsigned char* kb = lds + SLOT * BUF;
         const unsigned char* vb = kb + NS * PLANE;
 
@@ -514,7 +595,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
         UM_STAMP(2);
         // ---- additive bias: shifted-window mask (-100, unimatch/utils.py:106) and the ragged window tail -----
-        if (has_mask || (t + 1) * TK > a.n) {
+        if (need_bias(t)) {
             const float* bt = reinterpret_cast<const float*>(kb + BIAS_OFF) + clsq * TK + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -648,9 +729,132 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();  // ... and every wave's has; tile t is fully consumed, its slot may be refilled
         UM_STAMP(6);
     };
-    for (int t = t0; t < t1; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < t1) tile(std::integral_constant<int, 1>{}, t + 1);
+    // ---- the key walk.  Pass 0: the tiles that are computed unconditionally (all of them, unless the workgroup is class-uniform in
+    // a masked window); then the PROBE of the wholly masked tiles; pass 1: the masked tiles the probe could not clear.
+    const unsigned long long all_tiles = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull);
+    unsigned long long fail = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long rem = pass == 0 ? (all_tiles & ~probe) : fail;
+        auto next_tile = [&](int t) -> int {
+            if (bymask) {
+                if (rem == 0) return -1;
+                const int r = (int)__builtin_ctzll(rem);
+                rem &= rem - 1;
+                return r;
+            }
+            return t + 1 < t1 ? t + 1 : -1;
+        };
+        int t = bymask ? next_tile(0) : t0;
+        if (t < 0) break;
+        stage_prepare(t, lds);
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (;;) {
+            const int tn = next_tile(t);
+            tile(std::integral_constant<int, 0>{}, t, tn);
+            if (tn < 0) break;
+            t = next_tile(tn);
+            tile(std::integral_constant<int, 1>{}, tn, t);
+            if (t < 0) break;
+        }
+        if (pass == 1 || probe == 0) break;
+
+        // ---- probe phase.  Every key of a `probe` tile is of another class than all 128 queries of the workgroup: its logit is
+        // q.k / sqrt(C) - 100.  The own-class tiles are done, so m (the running row maximum, raw units) is a lower bound of the
+        // row's final maximum; a key whose logit stays UM_WATTN_SKIP_MARGIN below it contributes e^-margin of the largest term
+        // at most -- times <= 2048 keys still orders of magnitude below fp32 resolution of the sum (and of every output channel:
+        // the same weights multiply bounded values).  A tile is dropped iff that holds for EVERY (query, key) pair, judged on the
+        // hi.hi product alone: K_hi of up to 2 NS tiles lands in the plane areas of a ring slot, 8 MFMAs per tile (a sixth of the
+        // tile's 48), in-lane maximum, one vote.  The probe's error against the exact product is <= 2^-10 |q| |k| / sqrt(C) --
+        // part of the margin.  Tiles that fail the test in ANY wave are computed in pass 1 exactly as they were before round 6.
+        {
+            constexpr int G = 2 * NS;                                   // tiles per ring slot (one K_hi plane each)
+            unsigned long long pm = probe, myfail = 0;
+            unsigned* failw = reinterpret_cast<unsigned*>(lds + BUF + BIAS_OFF);      // slot 1's bias table is idle here
+            if (tid == 0) {
+                failw[0] = 0u;
+                failw[1] = 0u;
+            }
+            const float thr = m + a.skip_raw;
+            auto pstage = [&](int (&g)[G], unsigned char* base) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    g[i] = -1;
+                    if (pm != 0) {
+                        const int tp_ = (int)__builtin_ctzll(pm);
+                        pm &= pm - 1;
+                        g[i] = tp_;
+                        const unsigned* tp = tab + tp_ * TK + 8 * wave + ((lane >> 4) & 3);
+                        const unsigned o0 = 2u * (((unsigned)kvbase + (tp[0] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[0]);
+                        const unsigned o1 = 2u * (((unsigned)kvbase + (tp[4] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[1]);
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(
+                            (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(base + i * PLANE + (8 * wave) * 256));
+                        const unsigned short* b0 = a.kp;
+                        const unsigned short* b1 = a.kp - 512;
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                                     "global_load_lds_dwordx4 %2, %4 offset:1024\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(o0), "v"(o1), "s"(b0), "s"(b1), "s"(dst) : "memory");
+                    }
+                }
+            };
+            auto pcompute = [&](const int (&g)[G], const unsigned char* base) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    if (g[i] < 0) continue;
+                    f32x16 pa;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const i16x8 fh = *reinterpret_cast<const i16x8*>(base + i * PLANE + koff[ks]);
+                        pa = T::mfma(fh, qf[0][ks], pa);
+                    }
+                    float mx = pa[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, pa[r]);
+                    if (__any(!(mx <= thr))) myfail |= 1ull << g[i];
+                }
+                __builtin_amdgcn_s_setprio(0);
+            };
+            int g0[G], g1[G];
+            pstage(g0, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (;;) {
+                const bool more = pm != 0;
+                if (more) pstage(g1, lds + BUF);
+                pcompute(g0, lds);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!more) break;
+                const bool more2 = pm != 0;
+                if (more2) pstage(g0, lds);
+                pcompute(g1, lds + BUF);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!more2) break;
+            }
+            if (lane == 0 && myfail != 0) {
+                __hip_atomic_fetch_or(failw, (unsigned)myfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(failw + 1, (unsigned)(myfail >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            fail = (unsigned long long)__builtin_amdgcn_readfirstlane(failw[0]) |
+                   ((unsigned long long)__builtin_amdgcn_readfirstlane(failw[1]) << 32);
+        }
+    }
+    if (a.tile_census != nullptr && tid == 0) {
+        const unsigned long long nfail = (unsigned long long)__builtin_popcountll(fail);
+        const unsigned long long nfull = (unsigned long long)(bymask ? __builtin_popcountll(all_tiles & ~probe) : t1 - t0) + nfail;
+        __hip_atomic_fetch_add(a.tile_census + 0, nfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(a.tile_census + 1, (unsigned long long)__builtin_popcountll(probe), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(a.tile_census + 2, nfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(a.tile_census + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if constexpr (KSPLIT) {
         // The slots are written and read ONLY by 16-byte agent-scope accesses (sc1: write-through / L1-bypassing; the parts of a tile
@@ -862,6 +1066,48 @@ extern "C" int um_debug_set_trace(void* ptr) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_um_trace), &p, sizeof(p));
 }
 #endif
+
+// ---- tile census (um_window_attn_tile_census): four 64-bit counters in device memory, per device, counted by one thread per
+// workgroup while enabled: key tiles computed in full / wholly masked tiles probed / probed tiles that had to be computed after all /
+// workgroups.  Off by default (the kernels get a null pointer).
+static unsigned long long* g_tile_census[64] = {nullptr};
+static bool g_tile_census_on = false;
+static unsigned long long* wattn_census_ptr() {
+    if (!g_tile_census_on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_tile_census[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        (void)hipMemset(p, 0, 4 * sizeof(unsigned long long));
+        g_tile_census[dev] = (unsigned long long*)p;
+    }
+    return g_tile_census[dev];
+}
+
+extern "C" int um_window_attn_tile_census(int enable, unsigned long long* counts4) {
+    // counts4 != nullptr: the counters of the current device as of all work submitted so far (synchronises the device), then zeroed
+    if (counts4) {
+        counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
+        const bool was = g_tile_census_on;
+        g_tile_census_on = true;
+        unsigned long long* p = wattn_census_ptr();
+        g_tile_census_on = was;
+        if (p) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(counts4, p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemset(p, 0, 4 * sizeof(unsigned long long));
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    g_tile_census_on = enable != 0;
+    return 0;
+}
+
+#define UM_WATTN_SKIP_MARGIN 40.0f      // natural-log units below the running row maximum at which a masked key is dropped
 
 static int launch_window_attn(const unsigned short* pq, const unsigned short* pk, const unsigned short* pv, float* out,
                               int streams, int h, int w, int ldq, int ldkv, long q_plane_stride, long kv_plane_stride,
@@ -1102,6 +1348,12 @@ static int launch_window_attn(const unsigned short* pq, const unsigned short* pk
     a.mask_raw = -100.0f * sqrtf((float)UM_CHANNELS);
     static const float headroom = [] { const char* e = um_debug_env("UM_WATTN_HEADROOM"); return e ? (float)atof(e) : 8.f; }();
     a.headroom = (mode == 0) ? headroom : 0.f;
+    // masked-tile skip and heaviest-first order: a pure function of the call (diagnostic builds: UM_WATTN_NO_SKIP / UM_WATTN_NO_LPT)
+    static const bool no_skip = um_debug_env("UM_WATTN_NO_SKIP") != nullptr, no_lpt = um_debug_env("UM_WATTN_NO_LPT") != nullptr;
+    const bool shifted = shift_h > 0 || shift_w > 0;
+    a.skip_raw = (shifted && !no_skip) ? (100.0f - UM_WATTN_SKIP_MARGIN) * sqrtf((float)UM_CHANNELS) : -1.0f;
+    a.spx = (shifted && !no_skip && !no_lpt && streams % 8 == 0) ? streams / 8 : 0;
+    a.tile_census = wattn_census_ptr();
     ScopedKernelTimer timer(UM_K_WINDOW_ATTN, stream);
     if (wm && wq) {
         // the layer kernel (query projection + attention + merge + LayerNorm): wattn_plan; without workspace one workgroup per tile
