@@ -66,9 +66,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_16BIT = 2.5e15        # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 HEIGHT, WIDTH, BATCH = 512, 768, 8
 UM_K_COUNT = 12                 # include/unimatch_hip.h
-# what a memory-free MFMA loop with pseudo-random operands sustains on an MI355X under its power limit
-# (tools/mfma_peak.py, profiles/r01_mfma_sustained_peak.txt); the data-sheet peak is only reached with constant operands
-SUSTAINED_MFMA = 1.72e15
+REGIONS = 3                     # the K-step headline region is repeated this many times inside the run; `value` is the MEDIAN region
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_current.json')
 
 
@@ -85,10 +83,12 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (cfg2, default 8) / global batch (cfg4, default 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU / ROCm-eager baselines and the EPE legs')
     ap.add_argument('--no-fast', action='store_true', help='skip the extra bf16-mode measurement')
-    ap.add_argument('--streams', type=int, default=2,
-                    help='cfg2: the batch as this many concurrent forwards on separate HIP streams (unimatch_amd.streams: the halves fill '
-                         'one another\'s launch tails; 1 = one forward of the whole batch).  The roofline / breakdown pass always runs one '
-                         'forward with its launches serialised, and the line carries the one-forward throughput as `serial`')
+    ap.add_argument('--streams', type=int, default=None,
+                    help='default: the step is model(img0, img1, ...) as a caller of the reference would write it -- UniMatch.forward picks '
+                         'the number of concurrent forwards itself (unimatch_amd.streams.forward_parts: 2 at configs 2 / 4, the halves fill '
+                         'one another\'s launch tails).  N: force N concurrent forwards (1 = one forward of the whole batch).  The roofline / '
+                         'breakdown pass always runs one forward with its launches serialised, and the line carries the one-forward '
+                         'throughput as `serial`')
     ap.add_argument('--graph', action='store_true',
                     help='replay the HIP graph of the forward (unimatch_amd.graph) in the timed steps instead of launching eagerly '
                          '(measured on MI355X at config 2: 817.5 / 817.0 pairs/s against 818.6 / 819.1 eager -- the step is GPU-bound, '
@@ -167,7 +167,64 @@ def pmc_other_units(kernel_key, files):
         return None, None
 
 
-def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, precision, pmc_ok, bound='mfma'):
+def box_probe(lib, dev):
+    """What THIS box sustains, measured in this run (csrc/probe.hip): a ~25 ms memory-free MFMA loop with pseudo-random operands, a
+    float4 copy of 1 GiB (x 8), and a dependent-load chase.  MI355X boxes of the pool differ by several per cent; a reader can
+    normalise `value` and the roofline fractions by these."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sink = torch.zeros(1, device=dev)
+    iters = 20000
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+    lib.um_probe_mfma(sink.data_ptr(), 500, stream)
+    a, b_ = ev(), ev()
+    a.record()
+    lib.um_probe_mfma(sink.data_ptr(), iters, stream)
+    b_.record()
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    lib.um_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream)
+    c, d = ev(), ev()
+    c.record()
+    for _ in range(8):
+        lib.um_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream)
+    d.record()
+    # pointer ring: 1 Mi entries spread over 256 MiB (one entry per 256 bytes), visiting order a fixed odd-multiplier permutation
+    n = 1 << 20
+    idx = (torch.arange(n, dtype=torch.int64) * 741103597 + 12345) % n            # visiting order (odd multiplier: a permutation)
+    nxt = torch.empty(n, dtype=torch.int64)
+    nxt[idx] = idx.roll(-1)
+    ring = torch.zeros(n * 64, dtype=torch.int32)
+    ring[::64] = (nxt * 64).to(torch.int32)
+    ring = ring.to(dev)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    hops = 20000
+    lib.um_probe_chase(ring.data_ptr(), out.data_ptr(), 100, stream)
+    e, f = ev(), ev()
+    e.record()
+    lib.um_probe_chase(ring.data_ptr(), out.data_ptr(), hops, stream)
+    f.record()
+    # launch latency: 200 launches of the smallest kernel at hand
+    lib.um_probe_chase(ring.data_ptr(), out.data_ptr(), 1, stream)
+    g, h = ev(), ev()
+    g.record()
+    for _ in range(200):
+        lib.um_probe_chase(ring.data_ptr(), out.data_ptr(), 1, stream)
+    h.record()
+    torch.cuda.synchronize(dev)
+    mf = lib.um_probe_mfma_flops(iters) / (a.elapsed_time(b_) * 1e-3)
+    return {'mfma_sustained_tflops': round(mf / 1e12, 1), 'mfma_sustained_frac_of_peak': round(mf / PEAK_MFMA_16BIT, 4),
+            'hbm_copy_tbps': round(8 * 2 * nbytes / (c.elapsed_time(d) * 1e-3) / 1e12, 3),
+            'dependent_load_ns': round(e.elapsed_time(f) * 1e6 / hops, 1),
+            'back_to_back_launch_us': round(g.elapsed_time(h) * 1e3 / 200, 2),
+            'device': torch.cuda.get_device_name(dev),
+            'note': 'measured in this run (um_probe_*): random-operand fp16 MFMA loop on every SIMD (~25 ms), 8 float4 copies of 1 GiB '
+                    '(read + write counted), 20000 dependent loads over 256 MiB, 200 back-to-back single-wave launches'}
+
+
+def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, precision, pmc_ok, bound='mfma', sustained=None):
     """One roofline object: `achieved` = algorithmic FLOPs of the kernel's launches in a step / the summed hipEvent
     duration of those launches (breakdown pass).  With one launch shape per step this is per launch; with several (config 4: two
     scales) it is the time-weighted aggregate and `avg_launch_ms` the plain mean."""
@@ -187,8 +244,7 @@ def roofline_block(name, key, files, timing, flops_per_step, launches_per_step, 
             'avg_launch_ms': round(ms / n, 4), 'algorithmic_gflop_per_launch': round(flops_per_step / launches_per_step / 1e9, 2),
             'issued_mfma_frac': round(ach * issued / PEAK_MFMA_16BIT, 4),
             'mfma_busy': busy, 'mfma_busy_source': busy_note, 'lds_busy': lds_busy, 'valu_busy': valu_busy,
-            'sustained_mfma_peak_measured': SUSTAINED_MFMA / 1e12,
-            'issued_frac_of_sustained': round(ach * issued / SUSTAINED_MFMA, 4),
+            'issued_frac_of_box_sustained': (round(ach * issued / sustained, 4) if sustained else None),
             'duration_source': 'hipEvent pairs on the launch stream (um_timing_*), breakdown pass after the event-free headline region'}
 
 
@@ -320,17 +376,21 @@ def main():
 
     concurrent = {}
 
-    def timed(precision, steps, warmup, streams=None):
+    region_spread = []
+
+    def timed(precision, steps, warmup, streams=None, regions=1):
         """The headline region: K steps, barrier + synchronize on both sides, no per-kernel event inside."""
         model.set_precision(precision)
         launch['fwd'], launch['mode'] = model, 'eager'
         streams = args.streams if streams is None else streams
-        if streams > 1 and not args.graph:
-            from unimatch_amd.streams import ConcurrentUniMatch
-            if streams not in concurrent:
-                concurrent[streams] = ConcurrentUniMatch(model, parts=streams)
-            launch['fwd'] = concurrent[streams]
-            launch['mode'] = f'eager, {min(streams, b)} concurrent forwards of {b // min(streams, b)} pairs on {min(streams, b)} HIP streams'
+        model.launch_parts = streams                                  # None: UniMatch.forward's own plan (the drop-in call)
+        from unimatch_amd.streams import forward_parts
+        nparts = min(b, streams if streams is not None else forward_parts(fk['task'], fk['attn_type'], ck['num_scales'], ck['reg_refine'],
+                                                                           b, HEIGHT, WIDTH))
+        concurrent['parts'] = nparts
+        if nparts > 1:
+            launch['mode'] = (f'eager, model(img0, img1, ...): {nparts} concurrent forwards of {b // nparts} pairs on {nparts} HIP streams '
+                              + ('(forced by --streams)' if streams is not None else '(UniMatch.forward\'s own plan, streams.forward_parts)'))
         if args.graph:
             from unimatch_amd.graph import GraphedUniMatch
             launch['fwd'], launch['mode'] = GraphedUniMatch(model), 'hip_graph_replay'      # captured by the first warm-up step
@@ -341,31 +401,42 @@ def main():
         finish_gather()
         torch.cuda.synchronize()
         lib.um_timing_enable(0)
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        # per-step device time for the MEDIAN: one event between steps on the compute stream, read after the timed
-        # region (no host synchronisation inside it); `value` stays K steps / wall time of the bracketed region (the contract)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record()
-        for k in range(steps):
-            pred = step()
-            marks[k + 1].record()
-        finish_gather()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        # The region -- EXACTLY K steps bracketed by barrier + synchronize on both sides, max over ranks -- is run `regions` times back
+        # to back and the MEDIAN region is reported (round 6: one 0.18 s region is at the mercy of the box's clock ramp; min / max of
+        # the regions are on the line as `region_ms_per_step_min_max`).
+        results = []
+        for _ in range(regions):
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            # per-step device time for the MEDIAN step: one event between steps on the compute stream, read after the
+            # timed region (no host synchronisation inside it); `value` stays K steps / wall time of the bracketed region (the contract)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            t0 = time.perf_counter()
+            marks[0].record()
+            for k in range(steps):
+                pred = step()
+                marks[k + 1].record()
+            finish_gather()
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if distributed:
+                tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                elapsed = tmax.item()
+            results.append((elapsed, sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))))
+        results.sort(key=lambda r: r[0])
+        elapsed, steps_sorted = results[len(results) // 2]
         step_ms.clear()
-        step_ms.extend(sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps)))
-        if distributed:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = tmax.item()
+        step_ms.extend(steps_sorted)
+        region_spread.clear()
+        region_spread.extend([results[0][0] / steps * 1e3, results[-1][0] / steps * 1e3])
         mode_used = launch['mode']
         launch['fwd'], launch['mode'] = model, 'eager'             # the breakdown pass needs the library's per-launch events
+        model.launch_parts = 1                                      # ... of ONE forward with its launches serialised
         return elapsed, pred, mode_used
 
     def breakdown(steps):
@@ -406,7 +477,9 @@ def main():
         enc_wall = sum(a.elapsed_time(b_) for a, b_ in spans) / max(len(spans), 1)
         return out[0], out[1], enc_wall
 
-    elapsed, pred, launch_mode = timed(args.precision, args.steps, args.warmup)
+    elapsed, pred, launch_mode = timed(args.precision, args.steps, args.warmup, regions=REGIONS)
+    headline_parts = concurrent['parts']
+    headline_regions = [round(v, 3) for v in region_spread]
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     spread_ms = (step_ms[0], step_ms[-1])
     serial = None
@@ -416,6 +489,13 @@ def main():
                   'note': 'one forward of the whole per-GPU batch per step, launches serialised on one stream: the mode the roofline '
                           'durations, hot_path_ms_per_step and encoder_ms_per_step of this line are measured in'}
     hot_t, enc_t, enc_wall_ms = breakdown(args.steps)
+    # key-tile census of the attention launches of ONE forward (um_window_attn_tile_census): what the masked-tile skip executed
+    from unimatch_amd import _abi as _abi_mod
+    model.launch_parts = 1
+    _abi_mod.attn_tile_census(True)
+    step()
+    finish_gather()
+    tile_census = _abi_mod.attn_tile_census(False)
     other = 'fast' if args.precision == 'exact' else 'exact'
     extra = None
     if not args.no_fast:
@@ -429,6 +509,8 @@ def main():
             gather.close()
             dist.destroy_process_group()
         return
+    box = box_probe(lib, dev)
+    sustained = box['mfma_sustained_tflops'] * 1e12
 
     # ---- algorithmic work per step on THIS rank: per scale, feature map h x w, L = h w, C = 128, K splits -> n = L / K^2,
     # S = 2 b streams; 12 attention launches, 6 FFN launches per scale; global correlation + global propagation at scale 0
@@ -454,7 +536,7 @@ def main():
         lib.um_window_attn_plan(S, HEIGHT // 8, WIDTH // 8, HEIGHT // 16, WIDTH // 16, ctypes.byref(f_), ctypes.byref(r_), ctypes.byref(k_))
         ksplit = 'true' if r_.value > 0 else 'false'
         r1 = roofline_block('window_attn_kernel', f"window_attn_kernel<{tag}, true, {'true' if HipOps.fused_qproj else 'false'}, {ksplit}>",
-                            ['window_attn.hip', 'common.h'], hot[0], attn_flops, n_attn, precision, pmc_ok)
+                            ['window_attn.hip', 'common.h'], hot[0], attn_flops, n_attn, precision, pmc_ok, sustained=sustained)
         if r1 is not None and attn_fused:
             tot = (attn_flops + attn_fused) / (hot[0][0] * 1e-3 / (hot[0][1] / n_attn))
             issued = 3.0 if precision == 'exact' else 1.0
@@ -464,14 +546,14 @@ def main():
                 'algorithmic_gflop_per_launch': round((attn_flops + attn_fused) / n_attn / 1e9, 2), 'achieved': round(tot / 1e12, 2),
                 'frac': round(tot / PEAK_MFMA_16BIT, 4), 'issued_mfma_frac': round(tot * issued / PEAK_MFMA_16BIT, 4)}
         r2 = roofline_block('gsv4_kernel (global correlation / propagation)', f'gsv4_kernel<{tag}, 2>', ['global_match.hip', 'common.h'],
-                            hot[1], gsv_flops, n_gsv, precision, pmc_ok)
+                            hot[1], gsv_flops, n_gsv, precision, pmc_ok, sustained=sustained)
         fused_kv = all(getattr(HipOps, k_, False) for k_ in ('block_kv', 'fused_kv', 'fused_ffn', 'fused_qproj', 'fused_merge'))
         # with fused_kv every FFN launch but the last block's also executes the NEXT block's four k | v projections (um_ffn_kv_fwd):
         # `frac` prices what the launches execute (FFN + those projections); the FFN proper is in `ffn_only`
         kv_flops = sum(5 * 2.0 * S * h * w * 512 * 128 for h, w, _ in scales) if fused_kv else 0.0
         r3 = roofline_block('ffn_kernel (whole Transformer FFN' + (' + next block\'s k|v projections' if fused_kv else '') + ', one launch)',
                             f"ffn_kernel<{tag}, false, {'true' if fused_kv else 'false'}>", ['ffn.hip', 'common.h'],
-                            hot[10], ffn_flops + kv_flops, n_ffn, precision, pmc_ok)
+                            hot[10], ffn_flops + kv_flops, n_ffn, precision, pmc_ok, sustained=sustained)
         if r3 is not None:
             dur = hot[10][0] * 1e-3 / (hot[10][1] / n_ffn)
             r3['ffn_only'] = {'note': 'FFN FLOPs alone (transformer.py:141-144: 2 M 8C 3C per launch) over the same launch time'
@@ -486,6 +568,20 @@ def main():
                 {KERNEL_NAMES[k]: round(v[0] / steps, 4) for k, v in enc.items() if v[1]})
 
     roof, roof2, roof3 = blocks(hot_t, args.precision)
+    if roof is not None and tile_census.get('workgroups'):
+        # one (128-query workgroup, 32-key tile) pair = 4 * 128 * 32 * C algorithmic FLOP (QK^T + PV); a probe = the hi.hi third of
+        # QK^T = 1/6 of that.  `frac` / `achieved` above stay on SURVEY 8(d)'s FULL 4 L n C: dropped tiles are work not done, not
+        # throughput -- this object says how much of the algorithmic work the launches executed.
+        unit = 4.0 * 128 * 32 * c
+        full, probed, refused = tile_census['full'], tile_census['probed'], tile_census['probed_then_computed']
+        roof['masked_tile_skip'] = {
+            'tiles_computed': full, 'tiles_probed': probed, 'probed_tiles_computed_after_all': refused,
+            'tiles_dropped': probed - refused, 'workgroups': tile_census['workgroups'],
+            'executed_gflop_per_launch': round((full + probed / 6.0) * unit / n_attn / 1e9, 2),
+            'executed_frac_of_algorithmic': round((full + probed / 6.0) / max(full + probed - refused, 1), 4),
+            'note': 'key-tile census of the attention launches of one forward (um_window_attn_tile_census): wholly masked (workgroup, '
+                    'key tile) pairs of the shifted-window launches are probed (hi.hi product) and dropped only when every logit stays '
+                    '40 natural-log units below the running row maximum (unimatch/attention.py:88-89, unimatch/utils.py:84-108)'}
     hot_ms, hot_per, enc_ms, enc_per = sums(hot_t, enc_t, args.steps)
 
     # ---- baselines + EPE (rank 0 of the 1-GPU run only): bounded samples of the same workload shape, one pair
@@ -578,13 +674,15 @@ def main():
         'metric': 'image_pairs_per_sec', 'value': round(value, 3), 'unit': 'pairs/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'ms_per_step_median': round(median_ms, 3), 'ms_per_step_min_max': [round(spread_ms[0], 3), round(spread_ms[1], 3)],
+        'regions': REGIONS, 'region_ms_per_step_min_max': headline_regions,
+        'box': box,
         'pairs_per_sec_at_median': round((gb if cfg4 else b) / (median_ms * 1e-3), 2),
         'higher_is_better': True, 'scaling': 'strong' if cfg4 else 'weak', 'vs_baseline': None,
         'dtype': 'f16x2' if args.precision == 'exact' else 'bf16',
         'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective': gather_kind if distributed else None,
         'config': {'workload': workload,
                    'per_gpu_batch': b, 'global_batch': gb, 'precision': args.precision, 'launch_mode': launch_mode,
-                   'streams': (min(args.streams, b) if 'concurrent' in launch_mode else 1),
+                   'streams': headline_parts,
                    'precision_note': 'exact = fp16 hi+lo split MFMA operands (3 products), fp32 accumulate/softmax; every '
                                      'GEMM / convolution of the forward runs on the library\'s own split-fp16 MFMA kernels '
                                      '(no MIOpen, hipBLASLt or rocBLAS kernel in the forward)',

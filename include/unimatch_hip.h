@@ -125,6 +125,16 @@ long um_census_count(int variant);
  * part of [0] as well), [3] workgroups.  um_window_attn_tile_census(enable, counts4): counts4 != NULL synchronises the device,
  * copies the counters out and zeroes them; then the census is switched on / off as `enable` says. */
 int um_window_attn_tile_census(int enable, unsigned long long* counts4);
+/* Box probes (round 6, csrc/probe.hip): three kernels bench.py times inside its own run so that a bench line describes the box it was
+ * measured on (MI355X boxes of one pool differ by several per cent in what they sustain).  Asynchronous on `stream`; the caller times them.
+ *   um_probe_mfma(sink, iters): a memory-free loop of independent 32x32x16 fp16 MFMAs with pseudo-random operands on every SIMD;
+ *                               executes um_probe_mfma_flops(iters) FLOPs.  sink: one float of device memory (never written).
+ *   um_probe_copy(src, dst, bytes): float4 copy, bytes a multiple of 16 (reads `bytes`, writes `bytes`).
+ *   um_probe_chase(ring, out, hops): one lane follows ring[i] -> next index for `hops` dependent loads (the caller builds the ring). */
+double um_probe_mfma_flops(int iters);
+int um_probe_mfma(float* sink, int iters, void* stream);
+int um_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
+int um_probe_chase(const unsigned* ring, unsigned* out, int hops, void* stream);
 int um_timing_enable(int kernel_mask);   /* bit k set: time kernel id UM_K_* = k; -1: all; 0: off */
 int um_timing_collect(int kernel_id, double* total_ms, int* launches);
 /* ===================================== end of the measurement ABI ============================= */

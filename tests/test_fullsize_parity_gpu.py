@@ -92,12 +92,13 @@ def test_the_benchs_concurrent_half_batches_are_the_measured_kernels(legs):
     model = model.cuda()
     kw = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
     i0, i1 = i0.cuda(), i1.cuda()
+    model.launch_parts = 1
     whole = model(i0, i1, **kw)['flow_preds'][0]
-    wrapped = ConcurrentUniMatch(model, parts=2)
-    wrapped(i0, i1, **kw)                                             # first call: sequential, builds the caches
+    model.launch_parts = None                                         # round 6: the plain call picks two parts itself (streams.forward_parts)
+    model(i0, i1, **kw)                                               # first call: sequential, builds the caches
     lib = _abi.load()
     lib.um_census_enable(1)
-    got = wrapped(i0, i1, **kw)['flow_preds'][0]                      # concurrent
+    got = model(i0, i1, **kw)['flow_preds'][0]                        # concurrent
     torch.cuda.synchronize()
     census = {k: v for k, v in _abi.census(lib).items() if v}
     lib.um_census_enable(0)

@@ -1444,6 +1444,14 @@ def test_cost_volume_target_order_at_full_size():
     scale = max(1.0, natural.abs().max().item())
     assert (got - natural).abs().max().item() < 3e-6 * scale
     assert torch.equal(got[1, :, :, : w // 3], torch.zeros_like(got[1, :, :, : w // 3]))
+    # oracle leg at full size: images 0 (incoherent flow) and 1 (a third samples nothing) of the SORTED result
+    # against matching.py:86-123 evaluated in fp64 on the CPU
+    for img in (0, 1):
+        f0 = t0[img:img + 1].cpu().double().transpose(1, 2).reshape(1, C, h, w)
+        f1 = t1[img:img + 1].cpu().double().transpose(1, 2).reshape(1, C, h, w)
+        want = hp.local_corr_with_flow(f0, f1, flow[img:img + 1].cpu().double(), 4)
+        mx, mean = err(got[img:img + 1], want)
+        assert mean < 3e-6 * max(1.0, want.abs().max().item()) and mx < 3e-5 * max(1.0, want.abs().max().item()), (img, mx, mean)
     other = flow.clone()
     other[0] = torch.randn(2, h, w, generator=g).to(DEV) * 30.0               # different groups everywhere in image 0 ...
     got2 = o.local_corr_with_flow(t0, t1, other, h, w, 4)
@@ -1682,6 +1690,63 @@ def test_graph_capture_owns_its_split_workspaces():
     entry = next(iter(g3._graphs.values()))
     assert entry is not False and entry['workspaces'] and torch.equal(c, eager)
     assert set(ops._split_ws) == eager_keys and ops.workspace_owner is None
+
+
+def test_graph_of_a_forward_with_concurrent_parts_owns_one_workspace_set_per_part():
+    """a captured forward whose batch runs as two concurrent parts (UniMatch.forward's own plan, or forced) must
+    not share arrival counters / partial buffers / activation planes between the parts: owned buffers are keyed by (graph token,
+    part).  Small launches (key-split attention, hidden-split FFN) + the refinement's plane buffers; replay bitwise = eager."""
+    from unimatch_amd.graph import GraphedUniMatch
+    from unimatch_amd.streams import ConcurrentUniMatch
+    model, fk = _refine_model('gmflow_s2_rr6')
+    i0, i1 = synth_images(2, 128, 192, seed=21, kind='shift')
+    i0, i1 = i0.to(DEV), i1.to(DEV)
+    model.launch_parts = 2
+    try:
+        eager = model(i0, i1, **fk)['flow_preds'][0]                 # sequential first call
+        eager2 = model(i0, i1, **fk)['flow_preds'][0]                # concurrent
+        assert torch.equal(eager, eager2)
+        for wrap in (lambda m: m, lambda m: ConcurrentUniMatch(m, parts=2)):
+            graphed = GraphedUniMatch(wrap(model))
+            got = graphed(i0, i1, **fk)['flow_preds'][0]
+            entry = next(iter(graphed._graphs.values()))
+            assert entry is not False and torch.equal(got, eager)
+            lanes = {k[2][1] for k in entry['workspaces']}
+            assert lanes == {0, 1}, lanes
+            by_lane = {ln: {k[0]: t.data_ptr() for k, t in entry['workspaces'].items() if k[2][1] == ln} for ln in lanes}
+            assert set(by_lane[0]) == set(by_lane[1])
+            assert all(by_lane[0][name] != by_lane[1][name] for name in by_lane[0])
+            for _ in range(10):
+                again = graphed(i0, i1, **fk)['flow_preds'][0]
+            torch.cuda.synchronize()
+            assert torch.equal(again, eager)
+            assert model.ops.workspace_owner is None and model.ops.workspace_lane == 0
+    finally:
+        model.launch_parts = None
+
+
+def test_forward_chooses_its_launch_mode_per_call():
+    """the number of concurrent forwards is a property of UniMatch.forward, chosen by a pure function of the call
+    (streams.forward_parts).  A flow batch of four 512x768 pairs runs as two parts (bitwise the forwards of its halves); the same
+    model on two pairs, and a forced launch_parts = 1, run as one forward."""
+    from unimatch_amd.streams import forward_parts
+    model, i0, i1, fk = _graph_case('gmflow_s1', 512, 768, batch=8)
+    assert forward_parts('flow', fk['attn_type'], 1, False, 8, 512, 768) == 2
+    assert forward_parts('flow', fk['attn_type'], 1, False, 4, 512, 768) == 1
+    first = model(i0, i1, **fk)['flow_preds'][0]
+    assert model._runner is not None and len(model._runner._seen) == 1
+    second = model(i0, i1, **fk)['flow_preds'][0]                    # concurrent
+    torch.cuda.synchronize()
+    assert torch.equal(first, second)
+    halves = torch.cat([model(i0[:4], i1[:4], **fk)['flow_preds'][0], model(i0[4:], i1[4:], **fk)['flow_preds'][0]], 0)
+    assert len(model._runner._seen) == 1                             # four pairs: one forward each, nothing new in the runner
+    assert torch.equal(first, halves)
+    model.launch_parts = 1
+    whole = model(i0, i1, **fk)['flow_preds'][0]
+    model.launch_parts = None
+    assert torch.isfinite(whole).all() and whole.shape == first.shape
+    # one forward of 8 against two of 4: launch-size dependent summation orders only (random init amplifies them: compare medians)
+    assert (first - whole).abs().median().item() < 1e-2
 
 
 def test_sharded_model_through_the_rccl_gather_at_world_one():

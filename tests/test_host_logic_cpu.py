@@ -328,3 +328,19 @@ def test_concurrent_wrapper_splits_and_reassembles_a_batch():
     got = ConcurrentUniMatch(model, parts=2)(i0, i1, **kw)['flow_preds'][0]
     assert got.shape == whole.shape and (got - whole).abs().max().item() < 1e-4 * whole.abs().max().item()
     assert ConcurrentUniMatch(model, parts=1)(i0, i1, **kw)['flow_preds'][0].shape == whole.shape
+
+
+def test_forward_parts_plan_is_a_pure_function_of_the_call():
+    """``streams.forward_parts``: the five BASELINE configs at their own batch sizes -- two concurrent forwards
+    for configs 2 and 4 (per-GPU share and as written), one for stereo, depth, one pair and small frames."""
+    from unimatch_amd.streams import forward_parts
+    from unimatch_amd.synth import CONFIGS
+    plan = lambda name, b, h, w: forward_parts(CONFIGS[name][1]['task'], CONFIGS[name][1]['attn_type'], CONFIGS[name][0]['num_scales'],
+                                               CONFIGS[name][0]['reg_refine'], b, h, w)
+    assert plan('gmflow_s1', 1, 320, 448) == 1
+    assert plan('gmflow_s1', 8, 512, 768) == 2
+    assert plan('gmstereo_s2_rr3', 4, 512, 960) == 1
+    assert plan('gmflow_s2_rr6', 4, 512, 768) == 2 and plan('gmflow_s2_rr6', 32, 512, 768) == 2
+    assert plan('gmdepth_s1', 16, 480, 640) == 1
+    assert plan('gmflow_s1', 8, 128, 192) == 1 and plan('gmflow_s1', 2, 512, 768) == 1 and plan('gmflow_s1', 4, 512, 768) == 1
+    assert plan('gmflow_s1', 16, 512, 768) == 2 and plan('gmflow_s2_rr6', 8, 512, 768) == 1 and plan('gmstereo_s1', 8, 512, 960) == 1

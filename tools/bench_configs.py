@@ -16,15 +16,23 @@ RUNS = [  # (label, config, batch, H, W)
     ('cfg3 GMStereo-s2-rr3 4x512x960', 'gmstereo_s2_rr3', 4, 512, 960),
     ('cfg4 GMFlow-s2-rr6 4x512x768 (per-GPU share of B=32)', 'gmflow_s2_rr6', 4, 512, 768),
     ('cfg5 GMDepth-s1 16x480x640', 'gmdepth_s1', 16, 480, 640),
+    ('(6) GMFlow-s1 4x512x768', 'gmflow_s1', 4, 512, 768),
+    ('(7) GMFlow-s2-rr6 8x512x768', 'gmflow_s2_rr6', 8, 512, 768),
+    ('(8) GMFlow-s1 16x512x768', 'gmflow_s1', 16, 512, 768),
+    ('(9) GMStereo-s1 8x512x960', 'gmstereo_s1', 8, 512, 960),
+    ('(10) GMFlow-s2-rr6 32x512x768 (config 4 as written)', 'gmflow_s2_rr6', 32, 512, 768),
+    ('(11) GMFlow-s2-rr6 16x512x768', 'gmflow_s2_rr6', 16, 512, 768),
+    ('(12) GMFlow-s2-rr6 2x512x768', 'gmflow_s2_rr6', 2, 512, 768),
+    ('(13) GMFlow-s1 6x512x768', 'gmflow_s1', 6, 512, 768),
 ]
 ARGV = sys.argv[1:]
-ONLY = [int(v) for v in ARGV[ARGV.index('--only') + 1].split(',')] if '--only' in ARGV else [1, 2, 3, 4, 5]
+ONLY = [int(v) for v in ARGV[ARGV.index('--only') + 1].split(',')] if '--only' in ARGV else [1, 2, 3, 4, 5]    # 6-9: extra rows of the forward_parts table
 STEPS = int(ARGV[ARGV.index('--steps') + 1]) if '--steps' in ARGV else 5
 WEIGHTS = ARGV[ARGV.index('--weights') + 1] if '--weights' in ARGV else 'damped'
 WKW = CONDITIONED if WEIGHTS == 'conditioned' else dict(refine_gain=0.02)
 K4_FLAGS = int(ARGV[ARGV.index('--k4-flags') + 1]) if '--k4-flags' in ARGV else 0     # 2: natural tiles only (no target ordering), 1: per-pixel path
 REPEAT = int(ARGV[ARGV.index('--repeat') + 1]) if '--repeat' in ARGV else 1
-STREAMS = int(ARGV[ARGV.index('--streams') + 1]) if '--streams' in ARGV else 1       # > 1: the batch as concurrent forwards (unimatch_amd.streams)
+STREAMS = int(ARGV[ARGV.index('--streams') + 1]) if '--streams' in ARGV else 0       # N >= 1: force N concurrent forwards; 0: UniMatch.forward's own plan
 import ctypes
 from unimatch_amd import _abi
 for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
@@ -36,9 +44,7 @@ for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
     model = model.cuda()
     model.ops.k4_flags = K4_FLAGS
     plain = model
-    if STREAMS > 1:
-        from unimatch_amd.streams import ConcurrentUniMatch
-        model = ConcurrentUniMatch(plain, parts=STREAMS)
+    model.launch_parts = STREAMS if STREAMS >= 1 else None
     i0, i1 = synth_images(b, hh, ww, seed=3, kind='shift', normalized=(fk['task'] != 'flow'))
     kw = dict(fk)
     if fk['task'] == 'depth':
@@ -56,7 +62,9 @@ for idx, (label, name, b, hh, ww) in enumerate(RUNS, 1):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
         # the cost volume's launches of one more forward, timed by the library's own events (UM_K_COST_VOLUME = 4)
         lib.um_timing_enable(1 << 4)
+        plain.launch_parts = 1
         plain(i0, i1, **kw)
+        plain.launch_parts = STREAMS if STREAMS >= 1 else None
         torch.cuda.synchronize()
         ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
         lib.um_timing_collect(4, ctypes.byref(ms), ctypes.byref(cnt))

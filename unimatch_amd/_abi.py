@@ -91,6 +91,10 @@ SIGNATURES = {
     'um_census_enable': (_c_int, [_c_int]),
     'um_census_count': (ctypes.c_long, [_c_int]),
     'um_window_attn_tile_census': (_c_int, [_c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
+    'um_probe_mfma_flops': (ctypes.c_double, [_c_int]),
+    'um_probe_mfma': (_c_int, [_c_void_p, _c_int, _c_void_p]),
+    'um_probe_copy': (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    'um_probe_chase': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p]),
     'um_swin_attn_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_attn1d_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p, _c_size_t, _c_void_p]),
     'um_local_corr_softmax_1d': (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libunimatch_hip.so')
 SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', 'linear.hip', 'ffn.hip', 'conv.hip', 'nhwc_ops.hip', 'norm_ops.hip', 'upsample.hip',
-           'rccl_gather.hip', 'local_corr_mfma.hip', 'aliases.hip']
+           'rccl_gather.hip', 'local_corr_mfma.hip', 'aliases.hip', 'probe.hip']
 # hardware micro-benchmarks (um_debug_*): diagnostic builds only, never in the shipped library
 DIAG_SOURCES = ['microbench.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]

@@ -331,6 +331,7 @@ class UniMatch(nn.Module):
         self.debug_taps = None            # set to a dict to collect named intermediates (diagnostics only)
         self.check_weights = False        # True: fingerprint the parameters every forward (see _check_weight_print)
         self._weight_print = None
+        self._runner = None               # streams.PartRunner: the batch as concurrent forwards (see forward)
 
     # ------------------------------------------------------------------ hot-path backend
     def set_precision(self, precision):
@@ -451,13 +452,45 @@ class UniMatch(nn.Module):
         return self._convex(flow2, mask, is_depth=is_depth)
 
     # ------------------------------------------------------------------ forward
+    launch_parts = None      # None: streams.forward_parts() decides per call; an int forces that many concurrent forwards (1: never split)
+
     def forward(self, img0, img1, attn_type=None, attn_splits_list=None, corr_radius_list=None,
                 prop_radius_list=None, num_reg_refine=1, pred_bidir_flow=False, task='flow', intrinsics=None,
                 pose=None, min_depth=1. / 0.5, max_depth=1. / 10, num_depth_candidates=64,
                 depth_from_argmax=False, pred_bidir_depth=False, **kwargs):
+        """The reference's entry point (unimatch/unimatch.py:95-111), the only one a caller such as evaluate_flow.py:405-412 knows.
+
+        Round 6: HOW the batch is launched is decided here, by a pure function of the call (``streams.forward_parts``): either one
+        forward of the whole batch, or -- where the launches of one forward leave tails that a second forward fills (measured per
+        configuration) -- the batch as two forwards of contiguous sample ranges on two HIP streams, joined on the caller's
+        stream.  The samples of a batch are independent (unimatch.py:113-367 has no cross-sample operation), every part is bitwise
+        the plain forward of its samples."""
         if self.training:
             raise RuntimeError('this module implements inference only: call .eval() '
                                '(training-mode auxiliary outputs of the reference are out of scope)')
+        kw = dict(attn_type=attn_type, attn_splits_list=attn_splits_list, corr_radius_list=corr_radius_list,
+                  prop_radius_list=prop_radius_list, num_reg_refine=num_reg_refine, pred_bidir_flow=pred_bidir_flow, task=task,
+                  intrinsics=intrinsics, pose=pose, min_depth=min_depth, max_depth=max_depth,
+                  num_depth_candidates=num_depth_candidates, depth_from_argmax=depth_from_argmax, pred_bidir_depth=pred_bidir_depth)
+        parts = self.launch_parts
+        if parts is None:
+            parts = 1
+            if img0.is_cuda and self.debug_taps is None:
+                from .streams import forward_parts
+                parts = forward_parts(task, attn_type, self.num_scales, self.reg_refine, img0.shape[0], img0.shape[-2], img0.shape[-1])
+        parts = min(int(parts), img0.shape[0])
+        if parts <= 1:
+            return self._forward_one(img0, img1, **kw)
+        if self._runner is None:
+            from .streams import PartRunner
+            self._runner = PartRunner()
+        return self._runner.run(self, parts, img0, img1, kw)
+
+    def _forward_one(self, img0, img1, attn_type=None, attn_splits_list=None, corr_radius_list=None,
+                     prop_radius_list=None, num_reg_refine=1, pred_bidir_flow=False, task='flow', intrinsics=None,
+                     pose=None, min_depth=1. / 0.5, max_depth=1. / 10, num_depth_candidates=64,
+                     depth_from_argmax=False, pred_bidir_depth=False):
+        """One forward of the given samples on the current stream."""
         if pred_bidir_flow:
             assert task == 'flow'
         if task == 'depth':

@@ -321,7 +321,7 @@ class HipOps:
         if not nbytes:
             return None
         cache = self.__dict__.setdefault('_split_ws', {})
-        owner = self.workspace_owner if self.workspace_owner is not None else _stream()
+        owner = self._owner()
         key = (name, device, owner)
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes or (isinstance(name, tuple) and buf.numel() != nbytes):
@@ -336,11 +336,20 @@ class HipOps:
         return buf
 
     workspace_owner = None     # set by GraphedUniMatch around warm-up + capture (see _split_workspace)
+    workspace_lane = 0         # set by streams.PartRunner around each part's forward: the parts of a batch run on different streams
+
+    def _owner(self):
+        """Who owns the per-launch scratch requested now: the current stream, or -- under a graph's token -- (token, lane): a captured
+        forward that runs its batch as concurrent parts (UniMatch.forward, streams.PartRunner) has one set of arrival counters /
+        partial buffers / activation planes PER PART (round-5 ADVICE: keyed by the token alone, the two halves shared them on two streams)."""
+        if self.workspace_owner is not None:
+            return (self.workspace_owner, self.workspace_lane)
+        return _stream()
 
     def claim_workspaces(self, owner):
         """Remove and return every split workspace allocated under ``owner`` (the graph keeps them alive; nobody else can get them)."""
         cache = self.__dict__.setdefault('_split_ws', {})
-        mine = {k: cache.pop(k) for k in [k for k in cache if k[2] is owner]}
+        mine = {k: cache.pop(k) for k in [k for k in cache if isinstance(k[2], tuple) and k[2][0] is owner]}
         return mine
 
     def window_attention_qproj_merge(self, x, q_weight, k, v, streams, h, w, win_h, win_w, shift_h, shift_w, kv_rotate,
@@ -558,7 +567,7 @@ class HipOps:
         as for the split workspaces (:meth:`_split_workspace`): per stream, or per captured graph."""
         name = ('planes', tag, rows, ld)
         cache = self.__dict__.setdefault('_split_ws', {})
-        owner = self.workspace_owner if self.workspace_owner is not None else _stream()
+        owner = self._owner()
         device = torch.device(device)
         for k in [k for k in cache if isinstance(k[0], tuple) and k[0][:2] == name[:2] and k[0] != name and k[2] == owner
                   and torch.device(k[1]) == device]:

@@ -5,7 +5,8 @@ The samples of a batch are independent (InstanceNorm is per sample, every matchi
 workgroups on 512 resident slots (a half-empty last round at 37 % matrix-pipe busy), the FFN runs three synchronised rounds
 whose prologues / epilogues overlap with nothing.  Two forwards of half the batch on two streams fill one another's tails: while one half's
 launch drains, the other half's next launch starts.  Measured at config 2 (8 x 512x768): 9.67 -> 9.17 ms per step on one box, 9.20 -> 8.92 on
-another (+3 ... +5 %); four forwards of two pairs LOSE (10.4 ms: launches of a quarter of the chip).  Default two parts.
+another (+3 ... +5 %); four forwards of two pairs LOSE (10.4 ms: launches of a quarter of the chip).  Default two parts.  Round 6: this is how ``UniMatch.forward`` itself launches
+a batch where :func:`forward_parts` says so -- no wrapper needed; ``ConcurrentUniMatch`` remains as the switch that FORCES a part count.
 
 What it is not: a different computation.  Every part is a plain ``UniMatch.forward`` of its samples; results agree with the one-forward
 result to the summation order of the launch-size-dependent decompositions (stream-K split points of the global correlation), i.e. to the
@@ -16,9 +17,32 @@ import torch
 from .dist import shard_batch, shard_bounds
 
 
-class ConcurrentUniMatch(torch.nn.Module):
-    """``ConcurrentUniMatch(model, parts=2)(img0, img1, **kw)`` = ``model(img0, img1, **kw)`` computed as ``parts`` forwards of
-    contiguous sample ranges, each on its own stream, joined on the caller's stream.
+def forward_parts(task, attn_type, num_scales, reg_refine, batch, height, width):
+    """How many concurrent forwards ``UniMatch.forward`` cuts a batch into: a pure function of the call.
+
+    Two where the same-box table shows a gain, one where it shows a loss (``profiles/r06_forward_parts.txt``, MI355X, one box, forced 1
+    against forced 2; sizes in pairs of 512x768):
+
+        GMFlow scale-1 (swin K=2, global matching)            4: -1.6 %   6: -17 %   8: +2.7 %   16: +2.6 %
+        GMFlow scale-2 + 6 refinements (swin K=[2,8])         2: +2.5 %   4: +4.6 %  8: -7.0 %   16: -1.7 %   32: +3.4 %
+        GMStereo (1-D cross attention: HBM-bound launches)    scale-1 8: -6.3 %      scale-2 + 3 refinements 4: -6.5 %
+        GMDepth scale-1 16 x 480x640                          -12 %
+
+    i.e. BASELINE config 2 (8 pairs) and config 4 (its per-GPU share of 4 pairs, and the 32 as written) run as two parts; stereo,
+    depth, single pairs and the sizes in between run as one forward.  The gain comes from launch tails (a second forward's launches
+    fill them) and is lost where the co-running launches are bandwidth-bound or where half a batch no longer fills the chip."""
+    if task != 'flow' or batch < 2 or not attn_type or 'swin' not in attn_type or '1d' in attn_type:
+        return 1
+    pairs = batch * height * width / float(512 * 768)           # the table's unit
+    if num_scales == 1 and not reg_refine:
+        return 2 if pairs >= 7.5 else 1
+    if num_scales == 2 and reg_refine:
+        return 2 if (1.9 <= pairs <= 4.5 or pairs >= 30.0) else 1
+    return 1
+
+
+class PartRunner:
+    """Runs ``model._forward_one`` on ``n`` contiguous sample ranges, each on its own stream, joined on the caller's stream.
 
     The first forward of a geometry / argument set / parameter version runs the parts one after the other on the caller's stream:
     that is the forward that builds the caches later forwards only read (weight planes, position tables; buffers that are written per
@@ -26,31 +50,25 @@ class ConcurrentUniMatch(torch.nn.Module):
     shared entries (``set_precision``, ``invalidate_weights``, a weight edited in place): the parts only go to separate streams when the
     backend object is the one of the previous forward and that forward built no shared cache entry (``HipOps.cache_generation``)."""
 
-    def __init__(self, model, parts=2):
-        super().__init__()
-        if parts < 1:
-            raise ValueError('parts must be >= 1')
-        self.model = model
-        self.parts = parts
+    def __init__(self):
         self._streams = {}
         self._seen = set()
         self._backend = None                     # (id of the model's backend, its cache generation) after the previous forward
 
-    def _backend_state(self):
-        ops = getattr(self.model, 'ops', None)                     # (UniMatch creates its backend on first use)
+    @staticmethod
+    def _backend_state(model):
+        ops = getattr(model, '_ops', None)                         # (UniMatch creates its backend on first use)
         return (id(ops), getattr(ops, 'cache_generation', None))
 
-    def _key(self, img0, kw):
-        version = sum(p._version for p in self.model.parameters())
+    @staticmethod
+    def _key(model, n, img0, kw):
+        version = sum(p._version for p in model.parameters())
         small = tuple(sorted((k, v if isinstance(v, (int, float, bool, str, type(None))) else
                               tuple(v) if isinstance(v, (list, tuple)) else tuple(v.shape)) for k, v in kw.items()))
-        return (tuple(img0.shape), str(img0.device), small, version, torch.is_grad_enabled())
+        return (n, tuple(img0.shape), str(img0.device), small, version)
 
-    def forward(self, img0, img1, **kw):
+    def run(self, model, n, img0, img1, kw):
         batch = img0.shape[0]
-        n = min(self.parts, batch)
-        if n == 1:
-            return self.model(img0, img1, **kw)
         bidir = 2 if (kw.get('pred_bidir_flow') or kw.get('pred_bidir_depth')) else 1
 
         def part_inputs(r):
@@ -60,13 +78,24 @@ class ConcurrentUniMatch(torch.nn.Module):
                     pk[key] = shard_batch(pk[key], r, n)
             return shard_batch(img0, r, n), shard_batch(img1, r, n), pk
 
-        key = self._key(img0, kw)
-        concurrent = img0.is_cuda and key in self._seen and self._backend is not None and self._backend == self._backend_state()
+        def one(r, a0, a1, pk):
+            # buffers a captured graph owns are keyed by (graph token, lane): the parts of one capture must not share arrival counters
+            # or activation planes (HipOps._split_workspace)
+            ops = model.ops if img0.is_cuda else None
+            if ops is not None and hasattr(ops, 'workspace_lane'):
+                ops.workspace_lane = r
+            try:
+                return model._forward_one(a0, a1, **pk)['flow_preds']
+            finally:
+                if ops is not None and hasattr(ops, 'workspace_lane'):
+                    ops.workspace_lane = 0
+
+        key = self._key(model, n, img0, kw)
+        concurrent = img0.is_cuda and key in self._seen and self._backend is not None and self._backend == self._backend_state(model)
         outs = []
         if not concurrent:
             for r in range(n):
-                a0, a1, pk = part_inputs(r)
-                outs.append(self.model(a0, a1, **pk)['flow_preds'])
+                outs.append(one(r, *part_inputs(r)))
             self._seen.add(key)
         else:
             dev = img0.device
@@ -79,12 +108,12 @@ class ConcurrentUniMatch(torch.nn.Module):
                 s = streams[r]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
-                    outs.append(self.model(ins[r][0], ins[r][1], **ins[r][2])['flow_preds'])
+                    outs.append(one(r, *ins[r]))
             for r in range(n):
                 cur.wait_stream(streams[r])
                 for t in outs[r]:
                     t.record_stream(cur)                            # allocated on the part's stream, consumed on the caller's
-        self._backend = self._backend_state()
+        self._backend = self._backend_state(model)
         # every prediction of the list: [bidir * b_r, ...] per part -> [bidir * batch, ...] in the reference's [forward; backward] order
         counts = [shard_bounds(batch, r, n)[1] - shard_bounds(batch, r, n)[0] for r in range(n)]
         preds = []
@@ -92,3 +121,28 @@ class ConcurrentUniMatch(torch.nn.Module):
             pieces = [outs[r][i].reshape(bidir, counts[r], *outs[r][i].shape[1:]) for r in range(n)]
             preds.append(torch.cat(pieces, 1).reshape(bidir * batch, *outs[0][i].shape[1:]))
         return {'flow_preds': preds}
+
+
+class ConcurrentUniMatch(torch.nn.Module):
+    """``ConcurrentUniMatch(model, parts)(img0, img1, **kw)`` = ``model(img0, img1, **kw)`` with the number of concurrent forwards FORCED
+    to ``parts`` (``UniMatch.forward`` otherwise picks it per call, :func:`forward_parts`): A/B timing and tests."""
+
+    def __init__(self, model, parts=2):
+        super().__init__()
+        if parts < 1:
+            raise ValueError('parts must be >= 1')
+        self.model = model
+        self.parts = parts
+
+    @property
+    def _backend(self):
+        runner = getattr(self.model, '_runner', None)
+        return None if runner is None else runner._backend
+
+    def forward(self, img0, img1, **kw):
+        prev = self.model.launch_parts
+        self.model.launch_parts = self.parts
+        try:
+            return self.model(img0, img1, **kw)
+        finally:
+            self.model.launch_parts = prev
