@@ -50,18 +50,15 @@ def test_every_stage_within_twice_the_fp32_port(legs, cfg, kind):
 
 @pytest.mark.parametrize('cfg,which', ONE_SCALE_CASES)
 def test_one_scale_configs_stage_by_stage(legs, cfg, which):
-    """Configs 1, 2, 5: every stage within 2 x the fp32 port on both weight sets -- with ONE documented exception: the global
-    correlation softmax / global propagation on CONDITIONED weights (soft softmaxes: every one of the 6144 keys carries weight and a
-    lane's 3072 terms are one fp32 chain; 2.98 x the port at config 2, 2.06 x at config 5, 2.4e-5 px absolute -- located, explained and
-    priced in profiles/r05_stage_parity_one_scale.txt).  Those rows are held to 4 x the port AND to 1e-4 px absolute instead."""
+    """Configs 1, 2, 5: every stage within 2 x the fp32 port on both weight sets.  (Round 5 held the global correlation softmax /
+    global propagation rows of the CONDITIONED weights to 4 x: a lane's 3072 softmax terms were one fp32 chain.  Round 6's two-level
+    accumulation in gsv4_kernel -- level-2 sums parked in LDS, flushed every 8 key tiles -- removed the exception.)"""
     rows = sp.run_case(legs, cfg, which, 'shift', SEED, nsamples=ONE_SCALE_SAMPLES[cfg])
     names = {r['stage'] for r in rows}
     assert {'encoder', 'xfmr_s0', 'match_s0', 'prop_s0', 'mask_head', 'convex1', 'upsample'} <= names
     bad = []
     for r, line in zip(rows, sp.fmt_rows(rows)):
         worst, ok = sp.gate(r)
-        if not ok and which == 'conditioned' and r['stage'] in ('match_s0', 'prop_s0'):
-            ok = worst <= 4.0 and max(r['gpu_mean']) < 1e-4
         if not ok:
             bad.append(line)
     assert not bad, '\n' + '\n'.join(bad)

@@ -17,7 +17,7 @@ SOURCES = ['capi.hip', 'global_match.hip', 'window_attn.hip', 'local_ops.hip', '
 DIAG_SOURCES = ['microbench.hip']
 HEADERS = ['common.h', 'planes.h', 'timing.h', os.path.join('..', '..', 'include', 'unimatch_hip.h')]
 # per-file extras: the FFN kernel's hand-placed scalar VALU stream must not be re-packed into v_pk_* by the SLP vectorizer
-EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize'], 'window_attn.hip': ['-fno-slp-vectorize'],
+EXTRA_FLAGS = {'ffn.hip': ['-fno-slp-vectorize'], 'global_match.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form', '-Wno-inline-asm'], 'window_attn.hip': ['-fno-slp-vectorize'],
                'linear.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 

@@ -427,6 +427,21 @@ __global__ __launch_bounds__(256, 2) void gsv3_kernel(GsvArgs a) {
 //     accumulators of the next tile.  Exact as before: Ms stays an integer, every rescale is a power of two;
 //   * all LDS-DMA pieces of tile t+2 are issued in the first MFMA gaps of the iteration, a whole tile before their wait.
 // Grid: x = (batch, key split) fastest, so that the 24 query tiles sharing one key range run on one XCD (id % 8).
+// Round 6: the MFMAs of this kernel are compiler-visible again.  Rounds 2-5 issued them through inline asm (B operand constrained to
+// the accumulator file) -- LLVM's hazard recognizer does not look into an asm statement, so NOTHING kept the MAI -> VALU / VALU -> MAI wait
+// states except the hand-built distances of the shipped schedule, and a variant whose register allocation moved (the two-level
+// accumulation of round 5) got allocator-inserted copies / AGPR spill traffic of accumulator registers inside the hazard window:
+// data-dependent wrong results.  Now: the builtin, with Q pinned into AGPRs by an empty asm ("+a") right after its loads -- srcA / srcB
+// of a gfx950 MFMA may come from either file, so the value stays where it was pinned -- and `-mllvm -amdgpu-mfma-vgpr-form`
+// (build.py, this file only) so that the accumulators are selected in VGPRs although the function uses AGPRs.  Same instruction
+// stream as before (checked in the .s: A = VGPR fragment, B = a[..], C/D = v[..]), and the compiler inserts whatever wait states a
+// future change needs.
+#ifndef UM_GSV4_ASM_MFMA
+template <class T> struct GsvMfmaA {
+    static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) { d = T::mfma(a, b, d); }
+    static __device__ __forceinline__ void init(f32x16& d, i16x8 a, i16x8 b, const f32x16& c) { d = T::mfma(a, b, c); }
+};
+#else       // diagnostic builds: rounds 2-5's hand-issued form, for the same-box A/B (profiles/r06_gsv4_builtin_ab.txt)
 template <class T> struct GsvMfmaA;
 template <> struct GsvMfmaA<Fp16> {
     static __device__ __forceinline__ void acc(f32x16& d, i16x8 a, i16x8 b) {
@@ -444,15 +459,17 @@ template <> struct GsvMfmaA<Bf16> {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
     }
 };
+#endif
 
-// LDS-DMA with the destination formed in M0 by the same statement (s_add of a wave-uniform base and an immediate); M0 is not
-// saved: hipcc keeps nothing in M0 in this kernel (gfx9 LDS instructions do not need it; checked in the generated .s).
+// LDS-DMA with the destination formed in M0 by the same statement (s_add of a wave-uniform base and an immediate).  M0 is DECLARED
+// clobbered (round 6; hipcc honours it -- it re-materialises M0 for its own users behind the statement -- and warns that M0 is a
+// reserved register: -Wno-inline-asm in build.py); rounds 2-5 relied on "hipcc keeps nothing in M0 in this kernel".
 template <int IMM>
 __device__ __forceinline__ void gsv4_dma16(const void* base, unsigned byte_off, unsigned lds_base) {
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_base), "i"(IMM) : "memory", "scc");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_base), "i"(IMM) : "memory", "scc", "m0");
 }
 __device__ __forceinline__ void gsv4_dma4(const void* base, unsigned byte_off, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned gsv4_lds_addr(const unsigned char* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)p);
@@ -473,7 +490,19 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
     constexpr int VSLOT = NV * TK * 4;
     constexpr int VBASE = NKSLOT * KSLOT;
     constexpr int DUMP = VBASE + 4 * VSLOT;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[DUMP + 256];   // 3 K slots, 4 value slots, a dump row
+    // Round 6, two-level accumulation: a lane's running sums (l, acc) are a chain of 32 fp32 additions per tile -- 3072 terms over
+    // config 2's 96 key tiles, which with soft softmaxes (every key contributes) rounds ~8 x more often than the fp32 reference's
+    // blocked GEMM + softmax (stage row match_s0 of the conditioned weights: 2.98 x the port's error, profiles/r05_stage_parity_one_scale.txt).
+    // Every FLUSH tiles the lane adds its level-1 sums into level-2 sums parked in LDS (8 floats per thread: the offset they are
+    // relative to, l, acc -- [field][thread], conflict free, touched by the owning lane only: no synchronisation) and restarts
+    // level 1 from zero: chains of 256 + 12 instead of 3072, no extra live register in the pinned blocks.
+    constexpr int L2OFF = DUMP + 256;
+#ifdef UM_GSV4_ONE_LEVEL        // diagnostic builds: the single chain of rounds 2-5 (same-box A/B of what the flushes cost)
+    constexpr int FLUSH = 1 << 30;
+#else
+    constexpr int FLUSH = 8;
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L2OFF + 8 * 256 * 4];   // 3 K slots, 4 value slots, a dump row, level-2 sums
     using MF = GsvMfmaA<T>;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -611,15 +640,38 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         });
     };
 
+    // ---- level-2 sums of this thread: Ms2[2] (3e38: empty), l2[2], acc2[2][NV]
+    float* const lvl2 = reinterpret_cast<float*>(lds + L2OFF) + tid;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) lvl2[f * 256] = f < 2 ? 3.0e38f : 0.f;
+    // level 1 -> level 2.  The offset only ever moves towards larger maxima after the first tile (Ms decreases), so the factor that
+    // brings the parked sums to the current offset is a power of two <= 1 (exact); an empty level 2 (offset 3e38) gets factor 0.
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float f = fast_exp2(Ms[qb] - lvl2[qb * 256]);
+            lvl2[qb * 256] = Ms[qb];
+            lvl2[(2 + qb) * 256] = __builtin_fmaf(lvl2[(2 + qb) * 256], f, l[qb]);
+            l[qb] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) {
+                lvl2[(4 + 2 * qb + ch) * 256] = __builtin_fmaf(lvl2[(4 + 2 * qb + ch) * 256], f, acc[qb][ch]);
+                acc[qb][ch] = 0.f;
+            }
+        }
+    };
+
     // ---- renormalising path for one tile (first tile of a lane, or after the fast path left the safe range)
-    auto slow_update = [&](const GsvAcc4& y, const float* vt, float (&dd)[2]) __attribute__((always_inline)) {
+    auto slow_update = [&](auto first_c, const GsvAcc4& y, const float* vt, float (&dd)[2]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float tm = fmaxf(y.a[0][qb][0], y.a[1][qb][0]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(y.a[0][qb][r], y.a[1][qb][r]));
-            // the accumulators hold score + Ms.  New offset: the first tile of a lane fixes it; later only upwards.
-            const float d = (l[qb] == 0.f || tm > 0.f) ? ceilf(tm) : 0.f;
+            // the accumulators hold score + Ms.  New offset: the first tile of a segment fixes it; later only upwards (level 1 may
+            // be empty after a flush: that is not "no state")
+            const float d = (FIRST || tm > 0.f) ? ceilf(tm) : 0.f;
             const float f = (d > 0.f) ? fast_exp2(-d) : 1.f;       // d < 0 only while the state is still empty
             Ms[qb] -= d;
             l[qb] *= f;
@@ -798,7 +850,7 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         float dd[2];
-        slow_update(xa, reinterpret_cast<const float*>(lds + VBASE), dd);
+        slow_update(std::true_type{}, xa, reinterpret_cast<const float*>(lds + VBASE), dd);
         if (n > 1) shift_pending(xb, dd);
     }
     int s1 = 2, s2 = 0, s3 = 1;                                         // K slots of tiles i+1, i+2, i+3 at i = 1
@@ -818,7 +870,8 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             tail_update(y, vt);
         }
-        const bool bad = !(l[0] < GSV4_L_LIMIT) || !(l[1] < GSV4_L_LIMIT) || l[0] == 0.f || l[1] == 0.f;
+        // (an all-underflow tile after a flush leaves level 1 at zero: legitimate, the mass is in level 2)
+        const bool bad = !(l[0] < GSV4_L_LIMIT) || !(l[1] < GSV4_L_LIMIT);
         if (__builtin_amdgcn_ballot_w64(bad) != 0) {
             float dd[2];
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the pending MFMAs' results (asm) -> VALU
@@ -829,9 +882,10 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = a0[qb][ch];
-            slow_update(y, vt, dd);
+            slow_update(std::false_type{}, y, vt, dd);
             if (i + 1 < n) shift_pending(x, dd);
         }
+        if ((i & (FLUSH - 1)) == 0) flush();
         const int s0 = s1;
         s1 = s2;
         s2 = s3;
@@ -842,6 +896,13 @@ __global__ __launch_bounds__(256, 1) void gsv4_kernel(GsvArgs a) {
         if (i + 1 < n) iteration(i + 1, xa, xb);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flush();                                                            // the segment's totals are the level-2 sums
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        l[qb] = lvl2[(2 + qb) * 256];
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[qb][ch] = lvl2[(4 + 2 * qb + ch) * 256];
+    }
 
     // ---- merge the two half-waves' partial softmaxes and write (M = Ms: p = 2^(score + M))
 #pragma unroll
