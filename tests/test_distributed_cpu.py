@@ -140,43 +140,136 @@ def test_rank0_only_bootstrap_failure_reaches_every_rank():
     assert sorted(r[0] for r in results) == [0, 1] and all(r[1] and r[2] for r in results), results
 
 
+def _id_record(world, nonce, token=0x1122334455667788, magic=b'UMRCCL04', age_ms=0, ttl_ms=2000):
+    """A published id record as rank 0 writes it (csrc/rccl_gather.hip IdRecord): magic | world | nonce | stamp ms | deadline ms |
+    token | id."""
+    import struct
+    import time
+    now = int(time.time() * 1000) - age_ms
+    return magic + struct.pack('<iiqqQ', world, nonce, now, now + ttl_ms, token) + bytes(128)
+
+
 def test_id_file_readers_skip_records_of_another_job(tmp_path):
     """A record a crashed job left at the path (right magic, right world, fresh stamp) carries that job's nonce: a reader of
     another job must NOT take it -- it times out with a message naming its own nonce instead of joining a dead id."""
     import ctypes
-    import struct
     import time
     from unimatch_amd import _abi
     lib = _abi.load()
     path = tmp_path / 'id'
-    path.write_bytes(b'UMRCCL03' + struct.pack('<iiq', 2, 1234, int(time.time())) + bytes(128))
+    path.write_bytes(_id_record(2, 1234))
     comm = ctypes.c_void_p()
     t0 = time.time()
     rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321)
     assert rc == -5 and b'nonce 4321' in lib.um_last_error_string() and time.time() - t0 < 10
     assert path.exists()                                    # a reader never removes the record
-    assert not (tmp_path / 'id.ack1').exists()              # ... and does not acknowledge a record that is not its job's
-    # a record of the round-4 layout (magic 02) is not taken either, whatever its nonce
-    path.write_bytes(b'UMRCCL02' + struct.pack('<iiq', 2, 4321, int(time.time())) + bytes(128))
+    assert not list(tmp_path.glob('id.ack*'))               # ... and does not acknowledge a record that is not its job's
+    # a record of an earlier layout (magic 03 / 02) is not taken either, whatever its nonce
+    for magic in (b'UMRCCL03', b'UMRCCL02'):
+        path.write_bytes(_id_record(2, 4321, magic=magic))
+        assert lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321) == -5
+    # ... nor one whose shared deadline has passed (a job that died: its readers would wait for a go that never comes)
+    path.write_bytes(_id_record(2, 4321, age_ms=5000, ttl_ms=1000))
     assert lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 1, 4321) == -5
+    assert not list(tmp_path.glob('id.ack*'))
 
 
 def test_id_file_reader_acknowledges_and_gives_up_without_the_go(tmp_path):
-    """The three-step rendezvous (publish / ack / go): a reader that finds ITS job's record acknowledges it and then waits for rank
-    0's go; when another rank never shows up rank 0 never gives it, and the reader returns UM_ERR_COLLECTIVE after the timeout --
-    nobody is left inside ncclCommInitRank."""
+    """The three-step rendezvous (publish / ack / go): a reader that finds ITS job's record acknowledges it -- in a file that carries
+    the record's per-publish token -- and then waits for rank 0's go until the record's SHARED deadline (not its own clock: ADVICE
+    r05); when another rank never shows up rank 0 never gives it, and the reader leaves an abort marker, withdraws its ack and
+    returns UM_ERR_COLLECTIVE -- nobody is left inside ncclCommInitRank.  A `.go` of ANOTHER publish (a crashed job under the same
+    path and nonce) is not this rendezvous' go."""
     import ctypes
-    import struct
     import time
     from unimatch_amd import _abi
     lib = _abi.load()
     path = tmp_path / 'id'
-    path.write_bytes(b'UMRCCL03' + struct.pack('<iiq', 3, 77, int(time.time())) + bytes(128))
+    token = 0xabcdef0123456789
+    path.write_bytes(_id_record(3, 77, token=token, ttl_ms=1500))
+    (tmp_path / 'id.go').write_bytes(b'')                                # round-5 name of a stale go
+    (tmp_path / f'id.go.{0x1111111111111111:016x}').write_bytes(b'')     # the go of another publish
     comm = ctypes.c_void_p()
     t0 = time.time()
-    rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 2, 3, 1, 77)
-    assert rc == -5 and b"rank 0's go" in lib.um_last_error_string() and time.time() - t0 < 10
-    assert not comm.value and not (tmp_path / 'id.ack2').exists()       # its acknowledgement is withdrawn
+    rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 2, 3, 30, 77)     # own timeout 30 s: the record's 1.5 s rule
+    assert rc == -5 and b"rank 0's go" in lib.um_last_error_string() and 1.0 < time.time() - t0 < 10
+    assert not comm.value and not list(tmp_path.glob('id.ack2*'))       # its acknowledgement is withdrawn
+    assert (tmp_path / f'id.abort2.{token:016x}').exists()               # ... and it says so
+
+
+def test_id_file_reader_ignores_a_dead_jobs_go_and_follows_the_new_publish(tmp_path):
+    """a job that died inside ncclCommInitRank leaves its record AND its go behind, still fresh.  A reader of the
+    relaunch (same path, same nonce) that arrives before the new rank 0 acknowledges the stale record but must not take the stale go
+    (it is older than the reader's ack); when rank 0's new record replaces the stale one the reader withdraws its ack and
+    acknowledges the new token."""
+    import ctypes
+    import threading
+    import time
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    path = tmp_path / 'id'
+    stale, fresh = 0x0101010101010101, 0x0202020202020202
+    path.write_bytes(_id_record(2, 55, token=stale, ttl_ms=60000))
+    (tmp_path / f'id.go.{stale:016x}').write_bytes(b'')                  # the dead job's go
+    time.sleep(0.05)
+    out = {}
+
+    def reader():
+        comm = ctypes.c_void_p()
+        out['rc'] = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 1, 2, 30, 55)
+        out['err'] = lib.um_last_error_string()
+    th = threading.Thread(target=reader)
+    th.start()
+    time.sleep(0.5)
+    assert th.is_alive()                                                 # it did NOT run into ncclCommInitRank on the stale go
+    assert (tmp_path / f'id.ack1.{stale:016x}').exists()
+    path.write_bytes(_id_record(2, 55, token=fresh, ttl_ms=1000))        # the relaunch's rank 0 publishes (and then never gives a go)
+    time.sleep(0.4)
+    assert (tmp_path / f'id.ack1.{fresh:016x}').exists() and not (tmp_path / f'id.ack1.{stale:016x}').exists()
+    th.join(timeout=10)
+    assert not th.is_alive() and out['rc'] == -5 and b"rank 0's go" in out['err']
+    assert (tmp_path / f'id.abort1.{fresh:016x}').exists()
+
+
+def test_id_file_rank0_cleans_stale_files_and_refuses_late_go(tmp_path):
+    """Rank 0 removes every auxiliary file an earlier job left under the path before it publishes, publishes a record with a fresh
+    token and the shared deadline, and -- alone in a world of 2 -- gives up a margin BEFORE that deadline without ever writing a go."""
+    import ctypes
+    import struct
+    import threading
+    import time
+    from unimatch_amd import _abi
+    lib = _abi.load()
+    path = tmp_path / 'id'
+    for name in ('id.go', 'id.ack1', 'id.go.00000000deadbeef', 'id.ack1.00000000deadbeef', 'id.abort1.00000000deadbeef'):
+        (tmp_path / name).write_bytes(b'')
+    seen = {}
+
+    def watch():                                                   # what rank 0 published, read while it waits
+        t_end = time.time() + 5
+        while time.time() < t_end and 'rec' not in seen:
+            try:
+                raw = path.read_bytes()
+                if len(raw) == 168:
+                    seen['rec'] = raw
+                    seen['files'] = sorted(p.name for p in tmp_path.iterdir())
+            except OSError:
+                pass
+            time.sleep(0.01)
+    th = threading.Thread(target=watch)
+    th.start()
+    comm = ctypes.c_void_p()
+    t0 = time.time()
+    rc = lib.um_comm_init_file_nonce(ctypes.byref(comm), os.fsencode(str(path)), 0, 2, 2, 99)
+    dt = time.time() - t0
+    th.join()
+    if b'RCCL unavailable' in lib.um_last_error_string():
+        pytest.skip('no RCCL on this box: rank 0 cannot mint an id')
+    assert rc == -5 and b'acknowledge' in lib.um_last_error_string() and dt < 2.0      # deadline 2 s - margin 0.5 s
+    magic, world, nonce, stamp, deadline, token = struct.unpack('<8siiqqQ', seen['rec'][:40])
+    assert magic == b'UMRCCL04' and (world, nonce) == (2, 99) and deadline - stamp == 2000 and token not in (0, 0xdeadbeef)
+    assert seen['files'] == ['id'], seen['files']                  # the stale files were gone before the record appeared
+    assert not list(tmp_path.iterdir())                            # and rank 0 cleaned up after giving up
 
 
 def test_job_nonce_is_shared_by_ranks_with_different_parents(tmp_path, monkeypatch):

@@ -151,9 +151,10 @@ extern "C" int um_range_flags(unsigned* flags_out, int reset) {
         *flags_out = 0u;
         return 0;
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    volatile unsigned* v = g_range_host;
-    *flags_out = *v;
-    if (reset) *v = 0u;
+    // read-and-reset is ONE atomic exchange: a kernel's system-scope OR that lands between a separate load and store would be lost
+    // (round-5 ADVICE; UniMatch.forward calls this with reset = 1 while the previous forward's kernels may still be running).
+    // The word is process-wide (one per library instance, all devices and models): an overflow is reported by whichever forward
+    // reads the flags next.
+    *flags_out = reset ? __atomic_exchange_n(g_range_host, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(g_range_host, __ATOMIC_ACQUIRE);
     return 0;
 }

@@ -1033,7 +1033,10 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
         unsigned* ticket = reinterpret_cast<unsigned*>(lds);       // (rings and exchange buffers are dead)
         if (tid == 0) *ticket = __hip_atomic_fetch_add(a.hs_flag + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (*ticket != (unsigned)(nsplit - 1)) return;             // not the last arriver: done
+        const unsigned my_ticket = *ticket;
+        __syncthreads();             // every wave holds the ticket in a register: the row-store staging below reuses this LDS word
+                                     // (round-5 ADVICE: a delayed wave could have read staged data as its ticket)
+        if (my_ticket != (unsigned)(nsplit - 1)) return;           // not the last arriver: done
         asm volatile("buffer_inv sc1" ::: "memory");               // acquire side of the hand-off, last arriver only (window_attn.hip)
         if (tid == 0) __hip_atomic_store(a.hs_flag + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
         if (role == 1) return;
