@@ -21,7 +21,12 @@ x, y = (torch.randn(m, c, device='cuda', generator=g) * 1.5 for _ in range(2))
 w1 = torch.randn(8 * c, 2 * c, device='cuda', generator=g) * 0.06
 w2 = torch.randn(c, 8 * c, device='cuda', generator=g) * 0.03
 norm = torch.nn.LayerNorm(c).cuda()
-fn = lambda: ops.ffn_ln(x, y, w1, w2, norm)
+KV = '--kv' in sys.argv             # the FFN launch that also runs the next block's k | v projections (um_ffn_kv_fwd)
+if KV:
+    w4 = [torch.randn(c, c, device='cuda', generator=g) * 0.09 for _ in range(4)]
+    fn = lambda: ops.ffn_ln_kv(x, y, w1, w2, norm, w4)
+else:
+    fn = lambda: ops.ffn_ln(x, y, w1, w2, norm)
 nwg = m // 128
 buf = torch.zeros((nwg // 37 + 1) * 2 * (24 * 8 + 8), dtype=torch.int64, device='cuda')
 raw = ctypes.CDLL(_abi.LIB_PATH)
@@ -41,5 +46,8 @@ for i in range(b.shape[0]):
         continue
     d = (st[:, 1:6] - st[:, 0:5]).double()
     per = (st[1:, 0] - st[:-1, 0]).double()
-    print(f'wg {(i // 2) * 37:4d} role {i % 2} start {b[i, 192].item() - t0:9d} total {b[i, 193].item() - b[i, 192].item():8d} cyc  per-slice {per[2:].mean().item():7.0f}  ' +
+    pro, loop = st[0, 0].item() - b[i, 192].item(), b[i, 193].item() - st[0, 0].item()
+    epi = b[i, 194].item() - b[i, 193].item() if b[i, 194].item() else 0
+    kv = b[i, 195].item() - b[i, 194].item() if b[i, 195].item() else 0
+    print(f'wg {(i // 2) * 37:4d} role {i % 2} start {b[i, 192].item() - t0:9d} prologue {pro:6d} slices {loop:7d} epilogue {epi:6d} kv {kv:6d} ticks  per-slice {per[2:].mean().item():7.0f}  ' +
           '  '.join(f'{n} {d[2:23, j].mean().item():6.0f}' for j, n in enumerate(names)) + f'  between {(st[3:23, 0] - st[2:22, 5]).double().mean().item():5.0f}')

@@ -1129,6 +1129,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
             }
     }
 #endif
+#ifdef UM_FFN_TRACE
+    if (tracing) trace_buf[24 * 8 + 2] = __builtin_amdgcn_s_memtime();          // end of LayerNorm + residual + stores
+#endif
     if constexpr (KV4) {
         // ---- the next block's k | v projections of this tile (kv4_project): Y^T operand fragments from the normalised tile exactly as
         // the stand-alone kernel builds them from the fp32 tokens it reads back (same hi | lo split of the same fp32 values), handed to
@@ -1173,6 +1176,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(FfnArgs a) {
                 for (int ks = 0; ks < 8; ++ks) yf[pl][ks] = *reinterpret_cast<const i16x8*>(xch + (pl * 8 + ks) * 1024);
         }
         kv4_project<T, NS, true>(lds, lds + 65536, a.kv, yf, m0, wave, lane, aoff, neg1);
+#ifdef UM_FFN_TRACE
+        if (tracing) trace_buf[24 * 8 + 3] = __builtin_amdgcn_s_memtime();      // end of the k | v projection epilogue
+#endif
     }
 }
 
