@@ -41,8 +41,23 @@ def forward_parts(task, attn_type, num_scales, reg_refine, batch, height, width)
     return 1
 
 
+# side streams for parts 1 .. n-1, ONE set per device for the whole process (round 6: a set per model left every new model with
+# fresh streams, and HIP multiplexes streams onto a handful of hardware queues -- the fifth and sixth stream of a process landed on
+# the queue of another one and two "concurrent" parts ran one after the other plus the cross-stream waits: config 4 at 26.5 ms
+# instead of 21.2 when it ran after another configuration in the same process).  Part 0 runs on the caller's stream.
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, count):
+    pool = _SIDE_STREAMS.setdefault(str(dev), [])
+    while len(pool) < count:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:count]
+
+
 class PartRunner:
-    """Runs ``model._forward_one`` on ``n`` contiguous sample ranges, each on its own stream, joined on the caller's stream.
+    """Runs ``model._forward_one`` on ``n`` contiguous sample ranges -- part 0 on the caller's stream, the others on the process-wide
+    side streams of the device -- joined on the caller's stream.
 
     The first forward of a geometry / argument set / parameter version runs the parts one after the other on the caller's stream:
     that is the forward that builds the caches later forwards only read (weight planes, position tables; buffers that are written per
@@ -51,7 +66,6 @@ class PartRunner:
     backend object is the one of the previous forward and that forward built no shared cache entry (``HipOps.cache_generation``)."""
 
     def __init__(self):
-        self._streams = {}
         self._seen = set()
         self._backend = None                     # (id of the model's backend, its cache generation) after the previous forward
 
@@ -100,17 +114,17 @@ class PartRunner:
         else:
             dev = img0.device
             cur = torch.cuda.current_stream(dev)
-            streams = self._streams.setdefault(str(dev), [])
-            while len(streams) < n:
-                streams.append(torch.cuda.Stream(device=dev))
+            side = _side_streams(dev, n - 1)
             ins = [part_inputs(r) for r in range(n)]                # sliced on the caller's stream
-            for r in range(n):
-                s = streams[r]
-                s.wait_stream(cur)
-                with torch.cuda.stream(s):
-                    outs.append(one(r, *ins[r]))
-            for r in range(n):
-                cur.wait_stream(streams[r])
+            for s in side:
+                s.wait_stream(cur)                                  # (before part 0 is enqueued: the side parts depend on the inputs only)
+            outs = [None] * n
+            for r in range(1, n):
+                with torch.cuda.stream(side[r - 1]):
+                    outs[r] = one(r, *ins[r])
+            outs[0] = one(0, *ins[0])                               # part 0 on the caller's stream
+            for r in range(1, n):
+                cur.wait_stream(side[r - 1])
                 for t in outs[r]:
                     t.record_stream(cur)                            # allocated on the part's stream, consumed on the caller's
         self._backend = self._backend_state(model)
