@@ -43,7 +43,7 @@ if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_ke
 PMC=$(find /tmp/${TAG}_pmcl -name '*counter_collection.csv' | head -1)
 if [ -n "$PMC" ]; then python tools/pmc_summary.py "$PMC" window_attn gsv ffn_kernel > "$OUT/${TAG}_pmc_lds.json"; fi
 # then, in the build container:  python tools/pmc_roofline.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_pmc_sq.json gpurun_out/${TAG}_pmc_lds.json
-timeout 150 python tools/bench_configs.py --steps 10 2>&1 | grep cfg > "$OUT/${TAG}_all_configs.txt"
+timeout 200 python tools/bench_configs.py --only 1,2,3,4,5,10 --steps 10 2>&1 | grep -E "cfg|\(10\)" > "$OUT/${TAG}_all_configs.txt"
 (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_cfg4" -o p -- \
     python "$R/tools/profile_config.py" gmflow_s2_rr6 4 512 768 > "$OUT/${TAG}_cfg4.log" 2>&1 < /dev/null)
 rm -f "$OUT/${TAG}_cfg4"/*kernel_trace.csv

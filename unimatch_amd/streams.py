@@ -125,8 +125,6 @@ class PartRunner:
             outs[0] = one(0, *ins[0])                               # part 0 on the caller's stream
             for r in range(1, n):
                 cur.wait_stream(side[r - 1])
-                for t in outs[r]:
-                    t.record_stream(cur)                            # allocated on the part's stream, consumed on the caller's
         self._backend = self._backend_state(model)
         # every prediction of the list: [bidir * b_r, ...] per part -> [bidir * batch, ...] in the reference's [forward; backward] order
         counts = [shard_bounds(batch, r, n)[1] - shard_bounds(batch, r, n)[0] for r in range(n)]
@@ -134,6 +132,20 @@ class PartRunner:
         for i in range(len(outs[0])):
             pieces = [outs[r][i].reshape(bidir, counts[r], *outs[r][i].shape[1:]) for r in range(n)]
             preds.append(torch.cat(pieces, 1).reshape(bidir * batch, *outs[0][i].shape[1:]))
+        if concurrent:
+            # The side parts' outputs live in the side streams' allocator pools and were consumed (concatenated) on the caller's stream.
+            # Instead of Tensor.record_stream -- which parks every such block until an event of the caller's stream has completed and
+            # makes the caching allocator grow (a hipMalloc of a fresh segment in the middle of a timed loop: 25 - 55 ms hiccups were
+            # measured) -- the side streams are ordered behind the consumer: whatever runs on them next starts after the concatenation.
+            # (Inside a HIP-graph capture a side stream that waits on the capturing stream would have to be joined again before the
+            # capture ends: there the blocks are handed to the allocator's own cross-stream bookkeeping instead.)
+            if torch.cuda.is_current_stream_capturing():
+                for r in range(1, n):
+                    for t in outs[r]:
+                        t.record_stream(cur)
+            else:
+                for s in side:
+                    s.wait_stream(cur)
         return {'flow_preds': preds}
 
 
