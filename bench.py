@@ -18,24 +18,30 @@ resident in HBM; with N GPUs every rank runs its own batch (weak scaling, no dat
 predictions are all-gathered over RCCL (``um_allgather_preds`` of the library's C ABI = ncclAllGather, on a side stream
 so that the gather of step k overlaps step k+1) -- K timed steps contain K complete all-gathers.
 Rank 0 prints ONE JSON line; ``value`` is whole-job image-pairs/s in EXACT mode (the parity mode).
-Round 5: by default the step computes its 8 pairs as TWO concurrent forwards of 4 pairs on two HIP streams
-(``unimatch_amd.streams.ConcurrentUniMatch``, ``--streams 2``): the samples of a batch are independent, and the halves fill one
-another's launch tails (the attention launch alone leaves a half-empty last round); every half is bitwise the plain forward of its
-samples.  ``--streams 1`` = one forward of 8; the line carries that figure as ``serial`` either way.
+The step is ``model(img0, img1, ...)`` exactly as a caller of the reference writes it (evaluate_flow.py:405-412).  Round 6: ``UniMatch.forward``
+itself decides how the batch is launched (``unimatch_amd.streams.forward_parts``, a pure function of the call): at this workload two concurrent forwards
+of 4 pairs on two HIP streams -- the samples of a batch are independent, and the halves fill one another's launch tails; every half is bitwise the plain
+forward of its samples.  ``--streams N`` forces a count (1 = one forward of 8); the line carries the one-forward figure as ``serial`` either way.
 
 The headline region is EVENT-FREE (round 4): ``value`` / ``ms_per_step`` come from K steps bracketed by barrier + synchronize with
-no per-kernel event inside.  Directly after it a BREAKDOWN pass runs the same K steps twice with the library's per-kernel hipEvents
+no per-kernel event inside.  Round 6: that region is run three times back to back and the MEDIAN region is reported (``regions``,
+``region_ms_per_step_min_max``).  Directly after it a BREAKDOWN pass runs the same K steps twice with the library's per-kernel hipEvents
 (``um_timing_*``, recorded on the launch stream): once timing only the launches inside the CNN encoder, once only those outside it.
 
 Extra objects on the line:
   serial                throughput of the same K steps as ONE forward of the per-GPU batch per step (``config.streams`` = 1 when the
                         headline itself ran that way): the mode of every per-kernel figure below -- in the concurrent mode the
                         durations of kernels that share the GPU overlap and do not price a kernel.
+  box                   what THIS box sustains, measured in this run by the library's probe kernels (um_probe_*): a memory-free random-operand
+                        fp16 MFMA loop (``mfma_sustained_tflops``), a float4 copy (``hbm_copy_tbps``), a dependent-load chase, back-to-back launches.
+                        Boxes of the pool differ by several per cent; two lines differ in ``box`` by what they differ in ``value``.
   roofline              the dominant HIP kernel (windowed attention): algorithmic FLOPs per launch / its mean
                         launch duration from the breakdown pass, against the dense 16-bit MFMA peak; ``traffic`` / ``mfma_busy`` /
                         ``lds_busy`` / ``valu_busy`` come from rocprofv3 PMC passes kept in profiles/ and are nulled when the kernel
                         source has changed since those passes.  ``frac`` prices attention proper (4 L n C per stream); the merge Linear and query
-                        projection the same launch executes are in ``with_fused_linears``.
+                        projection the same launch executes are in ``with_fused_linears``; ``masked_tile_skip`` = the key-tile census of one
+                        forward (what the launches executed of the algorithmic FLOPs: wholly masked tiles of the shifted-window launches are
+                        probed and dropped under a bound -- ``frac`` stays on the FULL algorithmic FLOPs).
   roofline_global_corr  the same for ``gsv4_kernel`` (global correlation / propagation: the kernel the north star names).
   roofline_ffn          the same for ``ffn_kernel`` (the whole Transformer FFN in one launch, transformer.py:141-144).
   hot_path_ms_per_step  sum of the kernel durations of everything OUTSIDE the CNN encoder (SURVEY.md 8's path: Transformer,
@@ -700,10 +706,10 @@ def main():
         'serial': serial,
         'hot_path_pairs_per_sec': round((b if not cfg4 else b) / (hot_ms * 1e-3), 1) if hot_ms else None,
         'timing_note': 'value / ms_per_step: event-free region (barrier + synchronize around K steps), eager launches (--graph replays '
-                       'the forward as a HIP graph: no gain, the step is GPU-bound; config.launch_mode).  With --streams N > 1 (default 2) a '
-                       'step computes the per-GPU batch as N concurrent forwards on N HIP streams (unimatch_amd.streams: the parts fill one '
+                       'the forward as a HIP graph: no gain, the step is GPU-bound; config.launch_mode).  The step is model(...): UniMatch.forward\'s own '
+                       'plan (or --streams N) computes the per-GPU batch as N concurrent forwards on N HIP streams (unimatch_amd.streams: the parts fill one '
                        'another\'s launch tails; every part is bitwise the plain forward of its samples) and `serial` is the same K steps as '
-                       'one forward per step.  roofline durations (kernels alone on the GPU, one forward per step), '
+                       'one forward per step; `value` is the median of `regions` back-to-back regions of K steps.  roofline durations (kernels alone on the GPU, one forward per step), '
                        'hot_path_ms_per_step (kernel-duration sum of everything outside the CNN encoder = SURVEY 8\'s path) and '
                        'encoder_ms_per_step (the encoder\'s launches, SURVEY 2 #8, out of scope) come from a separate breakdown '
                        'pass of the same K steps with per-kernel hipEvents on the launch stream; hot_path_pairs_per_sec = this '
