@@ -135,8 +135,9 @@ class PartRunner:
         if concurrent:
             # The side parts' outputs live in the side streams' allocator pools and were consumed (concatenated) on the caller's stream.
             # Instead of Tensor.record_stream -- which parks every such block until an event of the caller's stream has completed and
-            # makes the caching allocator grow (a hipMalloc of a fresh segment in the middle of a timed loop: 25 - 55 ms hiccups were
-            # measured) -- the side streams are ordered behind the consumer: whatever runs on them next starts after the concatenation.
+            # made the caching allocator grow in steady state (1 - 2 hipMalloc of a fresh segment per ten steps, none without it; the one
+            # mechanism found for intermittent 25 - 55 ms hiccups) -- the side streams are ordered behind the consumer: whatever runs on
+            # them next starts after the concatenation.
             # (Inside a HIP-graph capture a side stream that waits on the capturing stream would have to be joined again before the
             # capture ends: there the blocks are handed to the allocator's own cross-stream bookkeeping instead.)
             if torch.cuda.is_current_stream_capturing():
