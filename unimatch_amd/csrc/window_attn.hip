@@ -761,6 +761,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (t < 0) break;
         }
         if (pass == 1 || probe == 0) break;
+#ifdef UM_WATTN_ASSUME_PASS          // diagnostic builds ONLY (wrong results for adversarial inputs): what the probe phase costs
+        break;                       // (profiles/r06_probe_cost.txt)
+#endif
 
         // ---- probe phase.  Every key of a `probe` tile is of another class than all 128 queries of the workgroup: its logit is
         // q.k / sqrt(C) - 100.  The own-class tiles are done, so m (the running row maximum, raw units) is a lower bound of the
