@@ -782,45 +782,54 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 failw[1] = 0u;
             }
             const float thr = m + a.skip_raw;
+            // (a group that runs out of tiles re-stages its last one: every group has G valid tiles, and the product below has no branch)
+            int last_tile = 0;
             auto pstage = [&](int (&g)[G], unsigned char* base) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    g[i] = -1;
                     if (pm != 0) {
-                        const int tp_ = (int)__builtin_ctzll(pm);
+                        last_tile = (int)__builtin_ctzll(pm);
                         pm &= pm - 1;
-                        g[i] = tp_;
-                        const unsigned* tp = tab + tp_ * TK + 8 * wave + ((lane >> 4) & 3);
-                        const unsigned o0 = 2u * (((unsigned)kvbase + (tp[0] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[0]);
-                        const unsigned o1 = 2u * (((unsigned)kvbase + (tp[4] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[1]);
-                        const unsigned dst = __builtin_amdgcn_readfirstlane(
-                            (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(base + i * PLANE + (8 * wave) * 256));
-                        const unsigned short* b0 = a.kp;
-                        const unsigned short* b1 = a.kp - 512;
-                        unsigned keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                                     "global_load_lds_dwordx4 %2, %4 offset:1024\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(o0), "v"(o1), "s"(b0), "s"(b1), "s"(dst) : "memory");
                     }
+                    g[i] = last_tile;
+                    const unsigned* tp = tab + last_tile * TK + 8 * wave + ((lane >> 4) & 3);
+                    const unsigned o0 = 2u * (((unsigned)kvbase + (tp[0] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[0]);
+                    const unsigned o1 = 2u * (((unsigned)kvbase + (tp[4] >> 2)) * (unsigned)a.ldkv + (unsigned)ssrc_k[1]);
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)(base + i * PLANE + (8 * wave) * 256));
+                    const unsigned short* b0 = a.kp;
+                    const unsigned short* b1 = a.kp - 512;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                                 "global_load_lds_dwordx4 %2, %4 offset:1024\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(b0), "s"(b1), "s"(dst) : "memory");
                 }
             };
+            // two tiles at a time on two accumulators: a lone chain of 8 dependent MFMAs behind 8 exposed LDS reads ran the matrix pipe at
+            // a fraction of its rate (the probe cost 2.5 x its MFMA share, profiles/r06_probe_cost.txt); interleaved, each chain's
+            // dependency and fragment latency hide under the other's MFMAs
             auto pcompute = [&](const int (&g)[G], const unsigned char* base) {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    if (g[i] < 0) continue;
-                    f32x16 pa;
+                for (int i = 0; i < G; i += 2) {
+                    f32x16 pa, pb;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+                    for (int r = 0; r < 16; ++r) pa[r] = pb[r] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
-                        const i16x8 fh = *reinterpret_cast<const i16x8*>(base + i * PLANE + koff[ks]);
-                        pa = T::mfma(fh, qf[0][ks], pa);
+                        const i16x8 fa = *reinterpret_cast<const i16x8*>(base + i * PLANE + koff[ks]);
+                        const i16x8 fb = *reinterpret_cast<const i16x8*>(base + (i + 1) * PLANE + koff[ks]);
+                        pa = T::mfma(fa, qf[0][ks], pa);
+                        pb = T::mfma(fb, qf[0][ks], pb);
                     }
-                    float mx = pa[0];
+                    float mxa = pa[0], mxb = pb[0];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, pa[r]);
-                    if (__any(!(mx <= thr))) myfail |= 1ull << g[i];
+                    for (int r = 1; r < 16; ++r) {
+                        mxa = fmaxf(mxa, pa[r]);
+                        mxb = fmaxf(mxb, pb[r]);
+                    }
+                    if (__any(!(mxa <= thr))) myfail |= 1ull << g[i];
+                    if (__any(!(mxb <= thr))) myfail |= 1ull << g[i + 1];
                 }
                 __builtin_amdgcn_s_setprio(0);
             };
