@@ -1725,6 +1725,34 @@ def test_graph_of_a_forward_with_concurrent_parts_owns_one_workspace_set_per_par
         model.launch_parts = None
 
 
+def test_small_launch_workspaces_survive_a_change_of_geometry():
+    """Round 6 regression: the split small-launch workspaces (key-split attention, hidden-split FFN) keep their arrival counters at the
+    head of the buffer, `tiles` of them -- a buffer left by ANOTHER geometry has that geometry's partial results where this launch's
+    counters must be zero.  One model, batch 1: 512x768, then 320x448, then 512x768 again must reproduce the first result bitwise (it
+    produced non-finite values); and a batch of 3 as parts of 2 + 1 pairs (three geometries through one stream in the sequential first
+    call) equals the forwards of its parts."""
+    model, i0, i1, fk = _graph_case('gmflow_s1', 512, 768, batch=3)
+    j0, j1 = synth_images(1, 320, 448, seed=12, kind='shift')
+    j0, j1 = j0.to(DEV), j1.to(DEV)
+    a = model(i0[:1], i1[:1], **fk)['flow_preds'][0]
+    b = model(j0, j1, **fk)['flow_preds'][0]
+    a2 = model(i0[:1], i1[:1], **fk)['flow_preds'][0]
+    b2 = model(j0, j1, **fk)['flow_preds'][0]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and torch.equal(a, a2) and torch.equal(b, b2)
+    two = model(i0[:2], i1[:2], **fk)['flow_preds'][0]
+    one = model(i0[2:], i1[2:], **fk)['flow_preds'][0]
+    model.launch_parts = 2
+    try:
+        first = model(i0, i1, **fk)['flow_preds'][0]                 # sequential: 2 pairs, then 1 pair, on one stream
+        again = [model(i0, i1, **fk)['flow_preds'][0] for _ in range(4)]     # concurrent
+    finally:
+        model.launch_parts = None
+    torch.cuda.synchronize()
+    assert torch.isfinite(first).all() and torch.equal(first, torch.cat([two, one], 0))
+    assert all(torch.equal(r, first) for r in again)
+    model.check_operand_range()
+
+
 def test_forward_chooses_its_launch_mode_per_call():
     """the number of concurrent forwards is a property of UniMatch.forward, chosen by a pure function of the call
     (streams.forward_parts).  A flow batch of four 512x768 pairs runs as two parts (bitwise the forwards of its halves); the same

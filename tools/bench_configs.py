@@ -24,6 +24,18 @@ RUNS = [  # (label, config, batch, H, W)
     ('(11) GMFlow-s2-rr6 16x512x768', 'gmflow_s2_rr6', 16, 512, 768),
     ('(12) GMFlow-s2-rr6 2x512x768', 'gmflow_s2_rr6', 2, 512, 768),
     ('(13) GMFlow-s1 6x512x768', 'gmflow_s1', 6, 512, 768),
+    ('(14) GMFlow-s1 2x512x768', 'gmflow_s1', 2, 512, 768),
+    ('(15) GMFlow-s1 3x512x768', 'gmflow_s1', 3, 512, 768),
+    ('(16) GMDepth-s1 2x480x640', 'gmdepth_s1', 2, 480, 640),
+    ('(17) GMDepth-s1 4x480x640', 'gmdepth_s1', 4, 480, 640),
+    ('(18) GMDepth-s1 8x480x640', 'gmdepth_s1', 8, 480, 640),
+    ('(19) GMStereo-s2-rr3 2x512x960', 'gmstereo_s2_rr3', 2, 512, 960),
+    ('(20) GMFlow-s1 4x320x448', 'gmflow_s1', 4, 320, 448),
+    ('(21) GMFlow-s1 8x320x448', 'gmflow_s1', 8, 320, 448),
+    ('(22) GMFlow-s1 16x320x448', 'gmflow_s1', 16, 320, 448),
+    ('(23) GMFlow-s1 2x320x448', 'gmflow_s1', 2, 320, 448),
+    ('(24) GMStereo-s1 2x512x960', 'gmstereo_s1', 2, 512, 960),
+    ('(25) GMStereo-s1 4x512x960', 'gmstereo_s1', 4, 512, 960),
 ]
 ARGV = sys.argv[1:]
 ONLY = [int(v) for v in ARGV[ARGV.index('--only') + 1].split(',')] if '--only' in ARGV else [1, 2, 3, 4, 5]    # 6-9: extra rows of the forward_parts table

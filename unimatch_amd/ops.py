@@ -324,7 +324,11 @@ class HipOps:
         owner = self._owner()
         key = (name, device, owner)
         buf = cache.get(key)
-        if buf is None or buf.numel() < nbytes or (isinstance(name, tuple) and buf.numel() != nbytes):
+        # EXACT size (round 6): the arrival counters sit at the head of the buffer and their count is the launch's tile count -- a bigger
+        # buffer left by another geometry has that geometry's partial results where this launch's counters must be zero (found with a
+        # batch of 3 as parts of 2 + 1 pairs on one stream: non-finite results; the same happened to ANY sequence of two small-launch
+        # geometries through one HipOps).  A geometry change on a stream costs one zero-fill.
+        if buf is None or buf.numel() != nbytes:
             if torch.cuda.is_current_stream_capturing():
                 # First request INSIDE a capture (a user's own torch.cuda.graph around the model, or a wrapper GraphedUniMatch could
                 # not install its owner token through): a capture-PRIVATE buffer -- allocated from the graph's pool, zeroed by a memset
