@@ -1760,15 +1760,19 @@ def test_forward_chooses_its_launch_mode_per_call():
     from unimatch_amd.streams import forward_parts
     model, i0, i1, fk = _graph_case('gmflow_s1', 512, 768, batch=8)
     assert forward_parts('flow', fk['attn_type'], 1, False, 8, 512, 768) == 2
-    assert forward_parts('flow', fk['attn_type'], 1, False, 4, 512, 768) == 1
+    assert forward_parts('flow', fk['attn_type'], 1, False, 2, 512, 768) == 1
     first = model(i0, i1, **fk)['flow_preds'][0]
     assert model._runner is not None and len(model._runner._seen) == 1
     second = model(i0, i1, **fk)['flow_preds'][0]                    # concurrent
     torch.cuda.synchronize()
     assert torch.equal(first, second)
+    model.launch_parts = 1
     halves = torch.cat([model(i0[:4], i1[:4], **fk)['flow_preds'][0], model(i0[4:], i1[4:], **fk)['flow_preds'][0]], 0)
-    assert len(model._runner._seen) == 1                             # four pairs: one forward each, nothing new in the runner
+    model.launch_parts = None
     assert torch.equal(first, halves)
+    seen = len(model._runner._seen)
+    pair = model(i0[:2], i1[:2], **fk)['flow_preds'][0]              # two pairs: one forward by plan, nothing new in the runner
+    assert len(model._runner._seen) == seen and pair.shape[0] == 2
     model.launch_parts = 1
     whole = model(i0, i1, **fk)['flow_preds'][0]
     model.launch_parts = None

@@ -331,16 +331,19 @@ def test_concurrent_wrapper_splits_and_reassembles_a_batch():
 
 
 def test_forward_parts_plan_is_a_pure_function_of_the_call():
-    """``streams.forward_parts``: the five BASELINE configs at their own batch sizes -- two concurrent forwards
-    for configs 2 and 4 (per-GPU share and as written), one for stereo, depth, one pair and small frames."""
+    """``streams.forward_parts``: the five BASELINE configs at their own batch sizes -- two concurrent forwards for
+    configs 2 - 5 (and config 4 as written), one for the single pair of config 1 and for batches whose halves no longer fill the chip
+    (the thresholds of profiles/r06_forward_parts.txt)."""
     from unimatch_amd.streams import forward_parts
     from unimatch_amd.synth import CONFIGS
     plan = lambda name, b, h, w: forward_parts(CONFIGS[name][1]['task'], CONFIGS[name][1]['attn_type'], CONFIGS[name][0]['num_scales'],
                                                CONFIGS[name][0]['reg_refine'], b, h, w)
     assert plan('gmflow_s1', 1, 320, 448) == 1
     assert plan('gmflow_s1', 8, 512, 768) == 2
-    assert plan('gmstereo_s2_rr3', 4, 512, 960) == 1
-    assert plan('gmflow_s2_rr6', 4, 512, 768) == 2 and plan('gmflow_s2_rr6', 32, 512, 768) == 2
-    assert plan('gmdepth_s1', 16, 480, 640) == 1
-    assert plan('gmflow_s1', 8, 128, 192) == 1 and plan('gmflow_s1', 2, 512, 768) == 1 and plan('gmflow_s1', 4, 512, 768) == 1
-    assert plan('gmflow_s1', 16, 512, 768) == 2 and plan('gmflow_s2_rr6', 8, 512, 768) == 1 and plan('gmstereo_s1', 8, 512, 960) == 1
+    assert plan('gmstereo_s2_rr3', 4, 512, 960) == 2 and plan('gmstereo_s2_rr3', 2, 512, 960) == 1
+    assert plan('gmflow_s2_rr6', 4, 512, 768) == 2 and plan('gmflow_s2_rr6', 32, 512, 768) == 2 and plan('gmflow_s2_rr6', 2, 512, 768) == 2
+    assert plan('gmdepth_s1', 16, 480, 640) == 2 and plan('gmdepth_s1', 2, 480, 640) == 1 and plan('gmdepth_s1', 4, 480, 640) == 2
+    assert plan('gmflow_s1', 2, 512, 768) == 1 and plan('gmflow_s1', 3, 512, 768) == 2 and plan('gmflow_s1', 16, 512, 768) == 2
+    assert plan('gmflow_s1', 4, 320, 448) == 1 and plan('gmflow_s1', 8, 320, 448) == 2 and plan('gmflow_s1', 8, 128, 192) == 1
+    assert plan('gmstereo_s1', 4, 512, 960) == 1 and plan('gmstereo_s1', 8, 512, 960) == 2
+    assert plan('gmflow_s2_rr6', 1, 512, 768) == 1

@@ -21,24 +21,30 @@ def forward_parts(task, attn_type, num_scales, reg_refine, batch, height, width)
     """How many concurrent forwards ``UniMatch.forward`` cuts a batch into: a pure function of the call.
 
     Two where the same-box table shows a gain, one where it shows a loss (``profiles/r06_forward_parts.txt``, MI355X, one box, forced 1
-    against forced 2; sizes in pairs of 512x768):
+    against forced 2 with the mechanics of :class:`PartRunner`; "size" = batch x height x width in units of 512 x 768 pixels):
 
-        GMFlow scale-1 (swin K=2, global matching)            4: -1.6 %   6: -17 %   8: +2.7 %   16: +2.6 %
-        GMFlow scale-2 + 6 refinements (swin K=[2,8])         2: +2.5 %   4: +4.6 %  8: -7.0 %   16: -1.7 %   32: +3.4 %
-        GMStereo (1-D cross attention: HBM-bound launches)    scale-1 8: -6.3 %      scale-2 + 3 refinements 4: -6.5 %
-        GMDepth scale-1 16 x 480x640                          -12 %
+        one-scale flow (GMFlow-s1)     512x768: 2 pairs -7 %, 3 +7.5 %, 4 +1 %, 6 +12 %, 8 +4.5 %, 16 +2.5 %
+                                       320x448: 2 pairs -36 %, 4 -25 % (size 1.5), 8 +6 % (size 2.9), 16 +11 %
+        one-scale depth (480x640)      2 pairs -20 % (size 1.6), 4 +11.6 % (size 3.1), 8 +12 %, 16 +6 %
+        one-scale stereo (512x960)     2 pairs -8 % (size 2.5), 4 +-0 (size 5), 8 +3.4 % (size 10)
+        flow, 2 scales + 6 refinements 2 pairs +4 %, 4 +7 %, 8 +4 %, 16 +2.8 %, 32 +3.1 %
+        stereo, 2 scales + 3 refin.    2 pairs +-0 (size 2.5), 4 +3.9 % (size 5)
+        three parts                    never better than two (config 2: 838 against 871 pairs/s; config 5: 1162 against 1181)
 
-    i.e. BASELINE config 2 (8 pairs) and config 4 (its per-GPU share of 4 pairs, and the 32 as written) run as two parts; stereo,
-    depth, single pairs and the sizes in between run as one forward.  The gain comes from launch tails (a second forward's launches
-    fill them) and is lost where the co-running launches are bandwidth-bound or where half a batch no longer fills the chip."""
-    if task != 'flow' or batch < 2 or not attn_type or 'swin' not in attn_type or '1d' in attn_type:
+    The gain comes from launch tails and per-workgroup fixed costs that a second forward's launches fill; it turns into a loss when
+    half a batch no longer fills the chip (small launches take the latency-bound split variants).  All five BASELINE configs except the
+    single pair of config 1 run as two parts.  (A first table, measured with a side-stream set per model and ``Tensor.record_stream``
+    on the parts' outputs, had shown losses for stereo, depth and mid-size batches: artefacts of those mechanics)"""
+    if batch < 2:
         return 1
-    pairs = batch * height * width / float(512 * 768)           # the table's unit
-    if num_scales == 1 and not reg_refine:
-        return 2 if pairs >= 7.5 else 1
-    if num_scales == 2 and reg_refine:
-        return 2 if (1.9 <= pairs <= 4.5 or pairs >= 30.0) else 1
-    return 1
+    size = batch * height * width / float(512 * 768)
+    if reg_refine:
+        need = 1.9 if task == 'flow' else 4.0
+    elif attn_type and '1d' in attn_type:                     # 1-D cross attention (stereo): bandwidth-bound launches need bigger halves
+        need = 6.0
+    else:
+        need = 2.8
+    return 2 if size >= need else 1
 
 
 # side streams for parts 1 .. n-1, ONE set per device for the whole process (round 6: a set per model left every new model with
