@@ -1753,6 +1753,33 @@ def test_small_launch_workspaces_survive_a_change_of_geometry():
     model.check_operand_range()
 
 
+@pytest.mark.parametrize('name', ['gmflow_s1', 'gmflow_s2_rr6', 'gmstereo_s2_rr3'])
+def test_results_do_not_depend_on_the_history_of_calls(name):
+    """One model, a shuffled sequence of batch / frame sizes (one forward and two concurrent parts, whole-tile and split small-launch
+    kernels, even and uneven parts), every input visited three times: a result is a function of the input alone -- bitwise equal at every
+    visit, whatever ran before it (the stale-workspace bug of round 6 was of this kind), finite, and no operand-range flag."""
+    import random
+    model, fk = _refine_model(name) if name != 'gmflow_s1' else (_graph_case(name, 64, 96)[0], CONFIGS[name][1])
+    cases = [(1, 320, 448), (2, 256, 384), (3, 512, 768), (4, 128, 192), (1, 512, 768), (5, 320, 448), (8, 256, 384), (2, 512, 768), (6, 512, 768)]
+    if name != 'gmflow_s1':
+        cases = [(1, 256, 384), (2, 256, 384), (3, 384, 512), (4, 256, 384), (2, 128, 192), (5, 256, 256), (3, 256, 384)]
+    inputs = {}
+    for i, (b, hh, ww) in enumerate(cases):
+        i0, i1 = synth_images(b, hh, ww, seed=200 + i, kind='shift', normalized=(fk['task'] != 'flow'))
+        inputs[(b, hh, ww)] = (i0.to(DEV), i1.to(DEV))
+    order = cases * 3
+    random.Random(7).shuffle(order)
+    seen = {}
+    for key in order:
+        out = model(*inputs[key], **fk)['flow_preds'][0]
+        assert torch.isfinite(out).all(), key
+        if key in seen:
+            assert torch.equal(out, seen[key]), key
+        else:
+            seen[key] = out.clone()
+    model.check_operand_range()
+
+
 def test_forward_chooses_its_launch_mode_per_call():
     """the number of concurrent forwards is a property of UniMatch.forward, chosen by a pure function of the call
     (streams.forward_parts).  A flow batch of four 512x768 pairs runs as two parts (bitwise the forwards of its halves); the same
