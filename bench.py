@@ -580,6 +580,7 @@ def main():
         # throughput -- this object says how much of the algorithmic work the launches executed.
         unit = 4.0 * 128 * 32 * c
         full, probed, refused = tile_census['full'], tile_census['probed'], tile_census['probed_then_computed']
+        roof['executed_gflop_per_launch'] = round((full + probed / 6.0) * unit / n_attn / 1e9, 2)      # (detail: masked_tile_skip)
         roof['masked_tile_skip'] = {
             'tiles_computed': full, 'tiles_probed': probed, 'probed_tiles_computed_after_all': refused,
             'tiles_dropped': probed - refused, 'workgroups': tile_census['workgroups'],
