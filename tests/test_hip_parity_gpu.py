@@ -1780,6 +1780,29 @@ def test_results_do_not_depend_on_the_history_of_calls(name):
     model.check_operand_range()
 
 
+def test_two_parts_with_bidirectional_flow_keep_the_reference_layout():
+    """pred_bidir_flow doubles the batch inside the model ([forward; backward], unimatch.py:139-141); with the batch cut into parts the
+    result must come back in that layout: rows [0, B) the forward flows of samples 0 .. B-1, rows [B, 2B) the backward ones -- bitwise
+    the rows of the parts' own forwards, for even and uneven parts."""
+    model, _, _, fk = _graph_case('gmflow_s1', 64, 96)
+    for b in (4, 3):
+        i0, i1 = synth_images(b, 128, 192, seed=33 + b, kind='shift')
+        i0, i1 = i0.to(DEV), i1.to(DEV)
+        model.launch_parts = 2
+        try:
+            first = model(i0, i1, pred_bidir_flow=True, **fk)['flow_preds'][0]
+            second = model(i0, i1, pred_bidir_flow=True, **fk)['flow_preds'][0]
+        finally:
+            model.launch_parts = 1
+        assert first.shape == (2 * b, 2, 128, 192) and torch.equal(first, second)
+        lo = 0
+        for n in (b - b // 2, b // 2):
+            alone = model(i0[lo:lo + n].contiguous(), i1[lo:lo + n].contiguous(), pred_bidir_flow=True, **fk)['flow_preds'][0]
+            assert torch.equal(first[lo:lo + n], alone[:n]) and torch.equal(first[b + lo:b + lo + n], alone[n:])
+            lo += n
+        model.launch_parts = None
+
+
 def test_forward_chooses_its_launch_mode_per_call():
     """the number of concurrent forwards is a property of UniMatch.forward, chosen by a pure function of the call
     (streams.forward_parts).  A flow batch of four 512x768 pairs runs as two parts (bitwise the forwards of its halves); the same
