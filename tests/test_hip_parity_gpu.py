@@ -1173,6 +1173,50 @@ def test_query_projection_prologue_matches_q_planes(ops, geo):
     assert err(got, ref)[0] < 2e-5, geo
 
 
+def test_key_split_launches_skip_masked_tiles_too(ops):
+    """Round 6: the key-split small launches (batch 1: the reference's own evaluation protocol) share the walk by rank -- part p of a
+    query tile takes the p-th share of the tiles to compute and of the tiles to probe.  Batch-1 config-2 geometry (one stream of 64x96,
+    2x2 windows of 1536 tokens, shift 16/24: 48 query tiles x 4 parts): census closed form, result equal to the q-planes kernel's; and
+    a masked key that must win the softmax (logit far above its row) is still found by the part whose share it falls into."""
+    s_, h, w, wh, ww, sh, sw = 1, 64, 96, 32, 48, 16, 24
+    c, m = 128, 64 * 96
+    x = rnd(1500, m, c, scale=1.5).to(DEV)
+    wq, wk, wv, wm = (rnd(1501 + i, c, c, scale=0.09).to(DEV) for i in range(4))
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    import ctypes
+    f_, r_, k_ = (ctypes.c_int() for _ in range(3))
+    ops.lib.um_window_attn_plan(s_, h, w, wh, ww, ctypes.byref(f_), ctypes.byref(r_), ctypes.byref(k_))
+    assert (f_.value, r_.value, k_.value) == (0, 48, 4)                   # all key-split, 4 parts
+    qp, _, _ = ops.linear_planes(x, (wq,))
+    kv, _, n2 = ops.linear_planes(x, (wk, wv))
+    ref = ops.window_attention_merge((qp, m, c, 0), (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, wh, ww, sh, sw, 0, wm, norm, x)
+    got, cen = _census(lambda: ops.window_attention_qproj_merge(x, wq, (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, wh, ww, sh, sw, 0, wm, norm, x))
+    assert cen == {'full': 12 * (48 + 24 + 24 + 12), 'probed': 12 * (24 + 24 + 36), 'probed_then_computed': 0, 'workgroups': 48 * 4}, cen
+    assert err(got, ref)[0] < 2e-5
+    # mask dominance through a key-split part: a key of another class whose logit beats the row by far more than 100
+    idx, label = hp.window_index(h, w, wh, ww, sh, sw)
+    win = idx.shape[0] - 1
+    a_tok = int(idx[win, 0])
+    other = [int(idx[win, j]) for j in range(idx.shape[1]) if label[win, j] != label[win, 0]]
+    # crafted through identity projections: q = x2 (Wq = I), k = v = xk (Wk = Wv = I)
+    eye = torch.eye(c).to(DEV)
+    x2 = rnd(1510, m, c).to(DEV)
+    x2[:, 0] = 0.0
+    x2[a_tok] = 0.0
+    x2[a_tok, 0] = 60.0
+    xk = x2.clone()
+    xk[a_tok, 0] = 0.0                                                     # (the query's own key must not carry the spike)
+    xk[other[-1], 0] = 60.0                                                # q = x2 (Wq = I), k = xk (Wk = I): logit 3600 / sqrt(128) = 318
+    qp2, _, _ = ops.linear_planes(x2, (eye,))
+    kv2, _, n22 = ops.linear_planes(xk, (eye, eye))
+    ref2 = ops.window_attention_merge((qp2, m, c, 0), (kv2, m, n22, 0), (kv2, m, n22, c), s_, h, w, wh, ww, sh, sw, 0, wm, norm, x2)
+    got2, cen2 = _census(lambda: ops.window_attention_qproj_merge(x2, eye, (kv2, m, n22, 0), (kv2, m, n22, c), s_, h, w, wh, ww, sh, sw, 0, wm, norm, x2))
+    assert cen2['probed_then_computed'] >= 1, cen2
+    assert err(got2, ref2)[0] < 2e-5
+    want = hp.window_attention(x2.double().cpu()[None], xk.double().cpu()[None], xk.double().cpu()[None], h, w, wh, ww, sh, sw)
+    assert (want[0, a_tok] - xk[other[-1]].double().cpu()).abs().max() < 1e-6   # the oracle agrees that the masked key dominates
+
+
 def test_fused_layer_matches_unfused_layer(ops, golden):
     """The whole FeatureTransformer through the fused tail vs the oracle (fp64) on the golden inputs."""
     g = golden('transformer')

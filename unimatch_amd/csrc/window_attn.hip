@@ -279,7 +279,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     //   per-lane bias table as before.
     // All wave-uniform (ballots); tile index = bit index, at most 64 tiles because the token table holds 2048 tokens.
     unsigned long long own_pure = 0, probe = 0;
-    if (!KSPLIT && has_mask && use_tab) {
+#ifdef UM_WATTN_KSPLIT_NOSKIP          // diagnostic builds: key-split launches walk every tile (the same-box A/B of profiles/r06_ksplit_skip.txt)
+    if (has_mask && use_tab && !KSPLIT) {
+#else
+    if (has_mask && use_tab) {
+#endif
         const int q0 = qt * 128, q1 = min(q0 + 127, a.n - 1);
         const int cq = cm_class(wc, q0);
         if (cq == cm_class(wc, q1)) {
@@ -289,7 +293,38 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (a.skip_raw >= 0.f) probe = __ballot(lane < ntiles && cf == cl && cf != cq);
         }
     }
-    const bool bymask = !KSPLIT && use_tab;                             // tile walk driven by a bit mask (else: the range [t0, t1))
+    const bool bymask = use_tab;                                        // tile walk driven by a bit mask (else: the range [t0, t1))
+    // KSPLIT (round 6: the key-split small launches -- batch-1 latency, the reference's own evaluation protocol -- skip as well): part p
+    // of a query tile takes the p-th share BY RANK of the tiles to compute and the p-th share of the tiles to probe; its running
+    // maximum covers its own share only, a weaker (still valid) lower bound of the row's final maximum -- a part without own-class
+    // tiles probes against -1e30, i.e. computes its share of the masked tiles.
+    // (only when a part's share is at least four probe tiles: below that -- config 1's 560-token windows, two probe tiles per part -- the
+    // probe phase's barriers cost a latency-bound launch more than the tiles it saves: +2.7 % measured, profiles/r06_ksplit_skip.txt)
+    if (KSPLIT && (int)__builtin_popcountll(probe) < 4 * nsplit) probe = 0;
+    unsigned long long walk = (ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull)) & ~probe;
+    if constexpr (KSPLIT) {
+        if (bymask && nsplit > 1) {
+            auto share = [&](unsigned long long mask) -> unsigned long long {
+                const int cnt = (int)__builtin_popcountll(mask);
+                const int lo = (part * cnt) / nsplit, hi = ((part + 1) * cnt) / nsplit;
+                unsigned long long out = 0;
+                int r = 0;
+                while (mask != 0) {
+                    const unsigned long long bit = mask & (0ull - mask);
+                    if (r >= lo && r < hi) out |= bit;
+                    mask ^= bit;
+                    ++r;
+                }
+                return out;
+            };
+            if (probe != 0) {
+                walk = share(walk);
+                probe = share(probe);
+            } else {                        // nothing to probe: the contiguous share [t0, t1) of all tiles, no rank loop
+                walk = (t1 >= 64 ? ~0ull : ((1ull << t1) - 1ull)) & ~((1ull << t0) - 1ull);
+            }
+        }
+    }
 
     // ---- this lane's query -----------------------------------------------------------------------
     const int tq = qt * 128 + wave * 32 + (lane & 31);
@@ -731,11 +766,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     // ---- the key walk.  Pass 0: the tiles that are computed unconditionally (all of them, unless the workgroup is class-uniform in
     // a masked window); then the PROBE of the wholly masked tiles; pass 1: the masked tiles the probe could not clear.
-    const unsigned long long all_tiles = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull);
     unsigned long long fail = 0;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        unsigned long long rem = pass == 0 ? (all_tiles & ~probe) : fail;
+        unsigned long long rem = pass == 0 ? walk : fail;
         auto next_tile = [&](int t) -> int {
             if (bymask) {
                 if (rem == 0) return -1;
@@ -746,19 +780,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             return t + 1 < t1 ? t + 1 : -1;
         };
         int t = bymask ? next_tile(0) : t0;
-        if (t < 0) break;
-        stage_prepare(t, lds);
+        if (t >= 0) {                      // (a key-split part may have no tile in a pass; its probe phase still runs)
+            stage_prepare(t, lds);
 #pragma unroll
-        for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (;;) {
-            const int tn = next_tile(t);
-            tile(std::integral_constant<int, 0>{}, t, tn);
-            if (tn < 0) break;
-            t = next_tile(tn);
-            tile(std::integral_constant<int, 1>{}, tn, t);
-            if (t < 0) break;
+            for (int i = 0; i < NPAIR; ++i) stage_pair(i, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (;;) {
+                const int tn = next_tile(t);
+                tile(std::integral_constant<int, 0>{}, t, tn);
+                if (tn < 0) break;
+                t = next_tile(tn);
+                tile(std::integral_constant<int, 1>{}, tn, t);
+                if (t < 0) break;
+            }
         }
         if (pass == 1 || probe == 0) break;
 #ifdef UM_WATTN_ASSUME_PASS          // diagnostic builds ONLY (wrong results for adversarial inputs): what the probe phase costs
@@ -862,7 +897,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if (a.tile_census != nullptr && tid == 0) {
         const unsigned long long nfail = (unsigned long long)__builtin_popcountll(fail);
-        const unsigned long long nfull = (unsigned long long)(bymask ? __builtin_popcountll(all_tiles & ~probe) : t1 - t0) + nfail;
+        const unsigned long long nfull = (unsigned long long)(bymask ? __builtin_popcountll(walk) : t1 - t0) + nfail;
         __hip_atomic_fetch_add(a.tile_census + 0, nfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_add(a.tile_census + 1, (unsigned long long)__builtin_popcountll(probe), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_add(a.tile_census + 2, nfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
