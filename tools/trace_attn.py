@@ -9,8 +9,9 @@ sys.path.insert(0, ROOT)
 from unimatch_amd import _abi
 from unimatch_amd.ops import HipOps
 ops = HipOps('exact'); lib = _abi.load()
-names = sys.argv[1].split(',') if len(sys.argv) > 1 else ['s0', 's1', 's2', 's3', 's4', 's5']
-s_, h, w, c = 16, 64, 96, 128
+args_ = [a for a in sys.argv[1:] if not a.startswith('--')]
+names = args_[0].split(',') if args_ else ['s0', 's1', 's2', 's3', 's4', 's5']
+s_, h, w, c = (2 if '--batch1' in sys.argv else 16), 64, 96, 128      # --batch1: the key-split small launch of one pair
 g = torch.Generator(device='cuda').manual_seed(0)
 norm = torch.nn.LayerNorm(c).cuda()
 wq, wk, wv, wm = (torch.randn(c, c, device='cuda', generator=g) * 0.09 for _ in range(4))
@@ -18,7 +19,7 @@ m = s_ * h * w
 x = torch.randn(m, c, device='cuda', generator=g) * 1.5
 kv, _, n2 = ops.linear_planes(x, (wk, wv))
 fn = lambda: ops.window_attention_qproj_merge(x, wq, (kv, m, n2, 0), (kv, m, n2, c), s_, h, w, 32, 48, 0, 0, s_ // 2, wm, norm, x)
-nwg = 768
+nwg = 768            # (--batch1: 384 key-split workgroups; the buffer is sized for the larger grid)
 buf = torch.zeros((nwg // 37 + 1) * (24 * 8 + 8), dtype=torch.int64, device='cuda')
 raw = ctypes.CDLL(_abi.LIB_PATH)
 for _ in range(2):
@@ -36,6 +37,7 @@ for i in range(b.shape[0]):
         continue
     ns = len(names)
     d = (st[:, 1:ns + 1] - st[:, 0:ns]).double()          # per-section cycles per tile
-    per_tile = (st[1:, 0] - st[:-1, 0]).double().mean().item()
+    nt = int((st[:, 0] > 0).sum().item())
+    per_tile = (st[1:nt, 0] - st[:nt - 1, 0]).double().mean().item() if nt > 1 else 0.0
     print(f'wg {i*37:4d} start {b[i,192].item()-t0:9d} total {b[i,193].item()-b[i,192].item():8d} cyc  per-tile {per_tile:7.0f}  ' +
-          '  '.join(f'{n} {d[2:, j].mean().item():6.0f}' for j, n in enumerate(names)))
+          '  '.join(f'{n} {d[1:max(nt, 2), j].mean().item():6.0f}' for j, n in enumerate(names)) + f'  tiles {nt}  first-tile-at {st[0, 0].item() - b[i, 192].item():6d}')
