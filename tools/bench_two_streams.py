@@ -15,6 +15,7 @@ ck, fk = CONFIGS['gmflow_s1']
 model = UniMatch(**ck).eval()
 model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}))
 model = model.cuda()
+model.launch_parts = 1               # round 6: UniMatch.forward would cut the batch itself (streams.forward_parts); this tool does the cutting
 b = 8
 i0, i1 = synth_images(b, 512, 768, seed=3, kind='shift', normalized=False)
 i0, i1 = i0.cuda(), i1.cuda()

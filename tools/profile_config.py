@@ -1,3 +1,4 @@
+"""One configuration under a profiler (tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats): python tools/profile_config.py <config> <batch> <H> <W>"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from unimatch_amd import UniMatch
@@ -7,6 +8,7 @@ ck, fk = CONFIGS[name]
 model = UniMatch(**ck).eval()
 model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, refine_gain=0.02))
 model = model.cuda()
+model.launch_parts = 1       # one forward, launches serialised: per-kernel durations of concurrent parts overlap and do not price a kernel
 i0, i1 = synth_images(b, hh, ww, seed=3, kind='shift', normalized=(fk['task'] != 'flow'))
 kw = dict(fk)
 if fk['task'] == 'depth':
